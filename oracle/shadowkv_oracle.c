@@ -1,0 +1,496 @@
+/*
+ * shadowkv_oracle.c -- CPU restatement of the ShadowKV decode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under shadowkv_amd/ may import, link or
+ * call this file.  Only tests/, __graft_entry__.smoke() and the cpu_baseline
+ * leg of bench.py use it, as the checker / the reported CPU baseline.
+ *
+ * Every function restates one stage of the reference's decode path with the
+ * rounding points of the reference's *kernels* (SURVEY.md section 8a, table
+ * "Rounding points").  Citations are into /root/reference.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - reorder / gather / d2d compaction: integer- and byte-exact, pinned by the
+ *     golden models of kernels/test_cached_gather_copy.cu:70-216 and by traces
+ *     of the reference's pure-PyTorch ShadowKVCache (tests/golden/).
+ *   - K rebuild + RoPE, V gather, landmark build: pinned by fixtures generated
+ *     from models/kv_cache.py:155-506 (tests/golden/make_golden.py).
+ *   - softmax statistics (CUTLASS EpilogueVisitorSoftmax, un-vendored) and
+ *     torch.topk tie order: PARITY UNPINNED against the CUDA path; the contract
+ *     used here is written out below and in DESIGN.md.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* bf16 helpers                                                              */
+/* ------------------------------------------------------------------------- */
+static inline float bf2f(uint16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* round-to-nearest-even f32 -> bf16, NaN stays NaN (what v_cvt_pk_bf16_f32 and
+ * CUDA __float2bfloat16_rn do). */
+static inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+/* bf16 arithmetic with one rounding per op (CUDA __hmul / __hadd on
+ * __nv_bfloat16: kernels/rope_new.cu:366-367). */
+static inline uint16_t bf_mul(uint16_t a, uint16_t b) { return f2bf(bf2f(a) * bf2f(b)); }
+static inline uint16_t bf_add(uint16_t a, uint16_t b) { return f2bf(bf2f(a) + bf2f(b)); }
+static inline uint16_t bf_neg(uint16_t a) { return (uint16_t)(a ^ 0x8000u); }
+
+/* ------------------------------------------------------------------------- */
+/* a4: landmark scoring  (models/kv_cache.py:1006-1019 -> batch_gemm_softmax) */
+/* ------------------------------------------------------------------------- */
+
+/* Contract of the f32 dot product (k = 128 = 16 lanes x 8 contiguous elements):
+ * lane l accumulates its 8 products as a sequential fma chain starting from 0,
+ * the 16 lane partials are summed by a balanced binary tree in natural order
+ * ((p0+p1)+(p2+p3))+...  bf16 x bf16 products are exact in f32, so fma == add
+ * of the exact product and the result is fully determined by this order.
+ * General k (multiple of 8): lanes = k/8 must be a power of two <= 64, the tree
+ * is the same balanced tree over `lanes` partials. */
+static float score_dot(const uint16_t *q, const uint16_t *x, int k) {
+    float p[64];
+    int lanes = k / 8;
+    for (int l = 0; l < lanes; ++l) {
+        float acc = 0.0f;
+        for (int j = 0; j < 8; ++j) acc = fmaf(bf2f(q[8 * l + j]), bf2f(x[8 * l + j]), acc);
+        p[l] = acc;
+    }
+    for (int w = lanes; w > 1; w >>= 1)
+        for (int i = 0; i < w / 2; ++i) p[i] = p[2 * i] + p[2 * i + 1];
+    return p[0];
+}
+
+/* exp for x <= 0 with a fully specified f32 op sequence (the reference uses
+ * CUTLASS fast_exp = ex2.approx, batch_gemm_softmax.h:248; not reproducible
+ * off-GPU, so the contract is this one; max rel. error ~1.5e-7):
+ *   x < -80 -> 0;  t = x*log2e; n = rint(t); r = fma(n,-ln2_hi,x); r = fma(n,-ln2_lo,r)
+ *   p = Horner degree 6 of exp(r) with fma; result = p * 2^n by exponent add. */
+static inline float spec_exp(float x) {
+    if (!(x >= -80.0f)) return 0.0f;
+    const float LOG2E = 1.44269504088896341f;
+    const float LN2_HI = 0.693145751953125f;      /* 0x3f317200 */
+    const float LN2_LO = 1.42860682030941723e-6f; /* ln2 - LN2_HI */
+    float t = x * LOG2E;
+    float n = rintf(t);
+    float r = fmaf(n, -LN2_HI, x);
+    r = fmaf(n, -LN2_LO, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    int32_t bits;
+    memcpy(&bits, &p, 4);
+    bits += ((int32_t)n) << 23;
+    memcpy(&p, &bits, 4);
+    return p;
+}
+
+/* e in [0, 2) -> trunc(e * 2^36) as an integer; sums of these are associative,
+ * so the softmax denominator does not depend on the summation order. */
+static inline uint64_t exp_to_fixed(float e) {
+    uint32_t bits;
+    memcpy(&bits, &e, 4);
+    int ex = (int)((bits >> 23) & 0xff);
+    if (ex == 0) return 0; /* zero / denormal: below 2^-36 anyway */
+    uint64_t mant = (uint64_t)((bits & 0x7fffffu) | 0x800000u);
+    int sh = ex - 127 - 23 + 36;
+    if (sh >= 0) return mant << sh;
+    if (sh <= -24) return 0;
+    return mant >> (-sh);
+}
+
+/* batch_gemm_softmax (kernels/functions.h:460, kernels/batch_gemm_softmax.cu:229-293,
+ * kernels/batch_gemm_softmax.h:207-302, :523-614).
+ *   A [batch][m][k] bf16 row-major (q), B [batch][n][k] bf16 (landmarks),
+ *   D, Softmax [batch][m][n] bf16, Norm / Sum [batch][m][ceil(n/256)] f32.
+ * Restated arithmetic:
+ *   D = bf16(alpha * dot)                      (f32 mul, one bf16 rounding)
+ *   mx = max_j float(D_j)                       (exact)
+ *   S  = sum_j trunc(2^36 * exp(float(D_j)-mx)) (integer, order-free)
+ *   inv = 1 / (float)(S * 2^-36)
+ *   P_j = bf16(exp(float(D_j)-mx) * inv)
+ * Norm[b*m*nblk + row] <- mx, Sum[b*m*nblk + row] <- inv  (partials are laid
+ * out [batch][tile][m], ldn = m, batch stride nblk*m: batch_gemm_softmax.cu
+ * :249-271; the final values land in tile 0's slots, the only entries the third
+ * kernel reads back, batch_gemm_softmax.h:274-275); other entries are left alone.
+ * beta is ignored (ScaleType::OnlyAlphaScaling, batch_gemm_softmax.cu:157-163). */
+ORACLE_API void oracle_batch_gemm_softmax(const uint16_t *A, const uint16_t *B, uint16_t *D,
+                                          float *Norm, float *Sum, uint16_t *Softmax,
+                                          int batch_count, int m, int n, int k, float alpha,
+                                          float beta) {
+    (void)beta;
+    int nblk = (n + 255) / 256;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < batch_count; ++b) {
+        for (int r = 0; r < m; ++r) {
+            const uint16_t *q = A + ((size_t)b * m + r) * k;
+            const uint16_t *Bb = B + (size_t)b * n * k;
+            uint16_t *Dr = D + ((size_t)b * m + r) * n;
+            uint16_t *Pr = Softmax + ((size_t)b * m + r) * n;
+            float mx = -INFINITY;
+            for (int j = 0; j < n; ++j) {
+                float v = alpha * score_dot(q, Bb + (size_t)j * k, k);
+                uint16_t d = f2bf(v);
+                Dr[j] = d;
+                float fd = bf2f(d);
+                if (fd > mx) mx = fd;
+            }
+            uint64_t S = 0;
+            for (int j = 0; j < n; ++j) S += exp_to_fixed(spec_exp(bf2f(Dr[j]) - mx));
+            float s = (float)((double)S * (1.0 / 68719476736.0));
+            float inv = 1.0f / s;
+            for (int j = 0; j < n; ++j) Pr[j] = f2bf(spec_exp(bf2f(Dr[j]) - mx) * inv);
+            if (Norm) Norm[(size_t)b * m * nblk + r] = mx;
+            if (Sum) Sum[(size_t)b * m * nblk + r] = inv;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5: group max + top-k + slot->chunk map (models/kv_cache.py:1023-1042)    */
+/* ------------------------------------------------------------------------- */
+/* P [blocks][groups][n] bf16 (all >= 0).  score[j] = max_g P[g][j] (exact, bf16).
+ * Selects the `topk` largest scores; membership under ties is NOT defined by
+ * the reference (torch.topk, CUDA) -- contract here: ties at the threshold go to
+ * the LOWEST landmark slot.  Output order: ascending landmark slot.  If
+ * landmark_idx != NULL the slot is mapped to its chunk id (k_landmark_idx
+ * gather, kv_cache.py:1039-1042).  Returns 0, or -1 if n < topk. */
+static int cmp_bf16_desc(const void *a, const void *c) {
+    float fa = bf2f(*(const uint16_t *)a), fc = bf2f(*(const uint16_t *)c);
+    return (fa < fc) - (fa > fc);
+}
+
+ORACLE_API int oracle_group_max_topk(const uint16_t *P, const int64_t *landmark_idx, int64_t *out,
+                                     int blocks, int groups, int n, int topk) {
+    if (n < topk) return -1;
+    uint16_t *score = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
+    uint16_t *tmp = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
+    for (int b = 0; b < blocks; ++b) {
+        const uint16_t *Pb = P + (size_t)b * groups * n;
+        for (int j = 0; j < n; ++j) {
+            uint16_t mx = Pb[j];
+            for (int g = 1; g < groups; ++g) {
+                uint16_t v = Pb[(size_t)g * n + j];
+                if (bf2f(v) > bf2f(mx)) mx = v;
+            }
+            score[j] = mx;
+        }
+        /* threshold = topk-th largest value */
+        memcpy(tmp, score, (size_t)n * sizeof(uint16_t));
+        qsort(tmp, (size_t)n, sizeof(uint16_t), cmp_bf16_desc);
+        float fthr = bf2f(tmp[topk - 1]);
+        int n_gt = 0;
+        for (int j = 0; j < n; ++j) n_gt += bf2f(score[j]) > fthr;
+        int need_eq = topk - n_gt;
+        int w = 0;
+        for (int j = 0; j < n && w < topk; ++j) {
+            float v = bf2f(score[j]);
+            int take = 0;
+            if (v > fthr) take = 1;
+            else if (v == fthr && need_eq > 0) { take = 1; --need_eq; }
+            if (take) {
+                out[(size_t)b * topk + w] = landmark_idx ? landmark_idx[(size_t)b * n + j] : (int64_t)j;
+                ++w;
+            }
+        }
+    }
+    free(score);
+    free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a6: chunk-cache diff (kernels/map.cuh:754-796, gather_copy.cu:259-307)    */
+/* ------------------------------------------------------------------------- */
+/* Per block (bs*heads of them): `cached` = the map_size chunk ids resident in
+ * the sparse region (slot i holds chunk cached[i]); `cur` = the map_size ids
+ * selected this step.  Outputs (cached is overwritten in place):
+ *   hits   = cur ids present in cached, sorted by their OLD slot (block_sort2
+ *            pass 1, map.cuh:508-539); offsets = old slot
+ *   misses = the rest, sorted ascending by chunk id (pass 2); offsets = chunk id
+ *   cnts[b] = number of hits
+ * Duplicate ids in `cached`: the reference's hash insert is racy; here the
+ * LOWEST slot wins, as in the golden model (std::map::insert keeps the first,
+ * test_cached_gather_copy.cu:83-87).  Ids are truncated to int32 like
+ * map.cuh:771,776.  Unlike the reference (silent no-op, gather_copy.cu:278-306)
+ * any map_size >= 1 is accepted. */
+typedef struct { int32_t off; int32_t key; } ok_pair;
+static int cmp_pair_off(const void *a, const void *b) {
+    const ok_pair *x = (const ok_pair *)a, *y = (const ok_pair *)b;
+    if (x->off != y->off) return x->off < y->off ? -1 : 1;
+    return 0;
+}
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+ORACLE_API void oracle_reorder_keys_and_compute_offsets(int64_t *cached_pos_ids,
+                                                        const int64_t *cur_pos_ids,
+                                                        int32_t *offsets, int32_t *cnts,
+                                                        int batch_size, int heads, int map_size) {
+    int blocks = batch_size * heads;
+    ok_pair *hits = (ok_pair *)malloc((size_t)map_size * sizeof(ok_pair));
+    int32_t *miss = (int32_t *)malloc((size_t)map_size * sizeof(int32_t));
+    for (int b = 0; b < blocks; ++b) {
+        int64_t *old = cached_pos_ids + (size_t)b * map_size;
+        const int64_t *cur = cur_pos_ids + (size_t)b * map_size;
+        int nh = 0, nm = 0;
+        for (int i = 0; i < map_size; ++i) {
+            int32_t key = (int32_t)cur[i];
+            int slot = -1;
+            for (int s = 0; s < map_size; ++s)
+                if ((int32_t)old[s] == key) { slot = s; break; }
+            if (slot >= 0) { hits[nh].off = slot; hits[nh].key = key; ++nh; }
+            else miss[nm++] = key;
+        }
+        /* stable w.r.t. equal offsets is irrelevant: equal offsets imply equal keys */
+        qsort(hits, (size_t)nh, sizeof(ok_pair), cmp_pair_off);
+        qsort(miss, (size_t)nm, sizeof(int32_t), cmp_i32);
+        int32_t *off = offsets + (size_t)b * map_size;
+        for (int i = 0; i < nh; ++i) { old[i] = hits[i].key; off[i] = hits[i].off; }
+        for (int i = 0; i < nm; ++i) { old[nh + i] = miss[i]; off[nh + i] = miss[i]; }
+        cnts[b] = nh;
+    }
+    free(hits);
+    free(miss);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7 / a8: chunk-row movement (kernels/copy.cuh:303-362, :649-687, :785-846) */
+/* ------------------------------------------------------------------------- */
+#define ROW_ELEMS 1024 /* one chunk row = 128 lanes x 16 B = 1024 bf16 (copy.cuh BLOCK_SIZE_CP x int4) */
+
+/* In-place compaction of hit rows inside the sparse region of a [blocks][stride]
+ * bf16 buffer: row i <- row offsets[i], i < cnt, with snapshot semantics (every
+ * source row is read before any row it could alias is written; the reference
+ * gets this from offsets[i] >= i and 32-row staging). Lengths/offsets are in
+ * bf16 elements like the reference's arguments (kv_cache.py:1090-1093). */
+static void compact_rows(uint16_t *buf, const int32_t *offsets, int cnt, size_t base) {
+    uint16_t *tmp = (uint16_t *)malloc((size_t)(cnt > 0 ? cnt : 1) * ROW_ELEMS * 2);
+    for (int i = 0; i < cnt; ++i)
+        memcpy(tmp + (size_t)i * ROW_ELEMS, buf + base + (size_t)offsets[i] * ROW_ELEMS, ROW_ELEMS * 2);
+    for (int i = 0; i < cnt; ++i)
+        memcpy(buf + base + (size_t)i * ROW_ELEMS, tmp + (size_t)i * ROW_ELEMS, ROW_ELEMS * 2);
+    free(tmp);
+}
+
+/* gather_copy_d2d_with_offsets (functions.h:97, gather_copy.cu:165-240) */
+ORACLE_API void oracle_gather_copy_d2d_with_offsets(uint16_t *keys, const int32_t *offsets,
+                                                    const int32_t *cnts, int batch_size, int heads,
+                                                    int gpu_k_length, int gpu_k_offset,
+                                                    int gpu_k_stride, int map_size) {
+    (void)gpu_k_length;
+    for (int b = 0; b < batch_size * heads; ++b)
+        compact_rows(keys, offsets + (size_t)b * map_size, cnts[b],
+                     (size_t)b * (size_t)gpu_k_stride + (size_t)gpu_k_offset);
+}
+
+/* gather_copy_with_offsets (functions.h:151, gather_copy.cu:332-419,
+ * copy.cuh:785-846): hits compacted in place, misses fetched from the host
+ * table: row i <- values[b*cpu_v_length + offsets[i]*ROW], i in [cnt, map_size). */
+ORACLE_API void oracle_gather_copy_with_offsets(const uint16_t *values, uint16_t *v_cache_buffer,
+                                                const int32_t *offsets, const int32_t *cnts,
+                                                int batch_size, int heads, int cpu_v_length,
+                                                int gpu_v_length, int gpu_v_offset,
+                                                int gpu_v_stride, int map_size) {
+    (void)gpu_v_length;
+    for (int b = 0; b < batch_size * heads; ++b) {
+        const int32_t *off = offsets + (size_t)b * map_size;
+        size_t base = (size_t)b * (size_t)gpu_v_stride + (size_t)gpu_v_offset;
+        compact_rows(v_cache_buffer, off, cnts[b], base);
+        for (int i = cnts[b]; i < map_size; ++i)
+            memcpy(v_cache_buffer + base + (size_t)i * ROW_ELEMS,
+                   values + (size_t)b * (size_t)cpu_v_length + (size_t)off[i] * ROW_ELEMS,
+                   ROW_ELEMS * 2);
+    }
+}
+
+/* gather_copy (functions.h:71, gather_copy.cu:81-146, copy.cuh:481-508): no
+ * cache, int64 position ids, every row fetched from the host table. */
+ORACLE_API void oracle_gather_copy(const uint16_t *values, uint16_t *v_cache_buffer,
+                                   const int64_t *position_ids, int batch_size, int heads,
+                                   int cpu_v_length, int gpu_v_length, int map_size) {
+    for (int b = 0; b < batch_size * heads; ++b)
+        for (int i = 0; i < map_size; ++i)
+            memcpy(v_cache_buffer + (size_t)b * (size_t)gpu_v_length + (size_t)i * ROW_ELEMS,
+                   values + (size_t)b * (size_t)cpu_v_length +
+                       (size_t)position_ids[(size_t)b * map_size + i] * ROW_ELEMS,
+                   ROW_ELEMS * 2);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a8: K rebuild  (kernels/batch_gather_gemm.cu:193-287)                     */
+/* ------------------------------------------------------------------------- */
+/* out[b][h][i][d] = bf16( sum_{j<rank} U[b][pos(i)][j] * SV[b][h][d][j] ),
+ * pos(i) = position_ids[b][h][i / chunk] * chunk + i % chunk, f32 accumulation
+ * (sequential fma chain over j here; the device kernel accumulates in MFMA
+ * order, so device-vs-oracle is a <=1 bf16 ulp comparison, not bit-exact --
+ * see DESIGN.md).  Rows of whole 128-row tiles below cnt*chunk are not
+ * written (early exit, gemm_universal_batch_gather_indices.h:736-738); callers
+ * must only rely on rows >= cnt*chunk.  U is shared by all heads
+ * (batch/num_heads, ...indices.h:717). */
+ORACLE_API void oracle_batch_gather_gemm(const uint16_t *U, const uint16_t *SV,
+                                         const int32_t *position_ids, uint16_t *output,
+                                         int batch_size, int heads, int seq_len, int embed_dim,
+                                         int rank, int sparse_budget, int chunk_size,
+                                         const int32_t *cnts) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < batch_size; ++b) {
+        for (int h = 0; h < heads; ++h) {
+            int cnt = cnts ? cnts[b * heads + h] : 0;
+            int first = (cnt * chunk_size / 128) * 128;
+            const int32_t *pid = position_ids + ((size_t)b * heads + h) * (sparse_budget / chunk_size);
+            for (int i = first; i < sparse_budget; ++i) {
+                long pos = (long)pid[i / chunk_size] * chunk_size + i % chunk_size;
+                const uint16_t *u = U + ((size_t)b * seq_len + (size_t)pos) * rank;
+                uint16_t *o = output + (((size_t)b * heads + h) * sparse_budget + i) * embed_dim;
+                for (int d = 0; d < embed_dim; ++d) {
+                    const uint16_t *sv = SV + (((size_t)b * heads + h) * embed_dim + d) * rank;
+                    float acc = 0.0f;
+                    for (int j = 0; j < rank; ++j) acc = fmaf(bf2f(u[j]), bf2f(sv[j]), acc);
+                    o[d] = f2bf(acc);
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a8: RoPE and push into the key cache (kernels/rope_new.cu)                */
+/* ------------------------------------------------------------------------- */
+/* NeoX half-split rotation in bf16 arithmetic, three roundings per output
+ * (rope_new.cu:360-367; same roundings as the pure-torch oracle,
+ * models/tensor_op.py:139-151).  If nvcc contracted hmul+hadd into an fma on
+ * the CUDA build that would be two roundings; not verifiable offline. */
+static inline void rope_llama_row(const uint16_t *x, const uint16_t *cs, uint16_t *o, int half) {
+    for (int t = 0; t < half; ++t) {
+        uint16_t x1 = x[t], x2 = x[t + half], c = cs[t], s = cs[t + half];
+        uint16_t o1 = bf_add(bf_mul(x1, c), bf_mul(bf_neg(x2), s));
+        uint16_t o2 = bf_add(bf_mul(x2, c), bf_mul(x1, s));
+        o[t] = o1;
+        o[t + half] = o2;
+    }
+}
+
+/* GLM: interleaved pairs (2t,2t+1), t<32, cos=cs[t], sin=cs[t+32]; dims 64..127
+ * copied (rope_new.cu:471-490). */
+static inline void rope_glm_row(const uint16_t *x, const uint16_t *cs, uint16_t *o) {
+    for (int t = 0; t < 32; ++t) {
+        uint16_t x1 = x[2 * t], x2 = x[2 * t + 1], c = cs[t], s = cs[t + 32];
+        uint16_t o1 = bf_add(bf_mul(x1, c), bf_mul(bf_neg(x2), s));
+        uint16_t o2 = bf_add(bf_mul(x2, c), bf_mul(x1, s));
+        o[2 * t] = o1;
+        o[2 * t + 1] = o2;
+    }
+    for (int t = 64; t < 128; ++t) o[t] = x[t];
+}
+
+/* apply_rotary_pos_emb_push_cache_opt[_glm] (functions.h:362,:396;
+ * rope_new.cu:321-411, :429-534).  Strides in elements.  Rows of chunks below
+ * cnts[b][h] are skipped; rows at or past offset_end are skipped. */
+ORACLE_API void oracle_rope_push_cache(const uint16_t *x, const uint16_t *cos_sin,
+                                       const int32_t *position_ids, uint16_t *output_cache,
+                                       const int32_t *cnts, int batch_size, int heads, int seq_len,
+                                       int embed_dim, long stride_xb, long stride_xh, long stride_xs,
+                                       long stride_cos_sin, long stride_pid_b, long stride_pid_h,
+                                       long stride_pid_s, long stride_ob, long stride_oh,
+                                       long stride_os, int offset_start, int offset_end,
+                                       int half_dim, int chunk_size, int glm) {
+    (void)embed_dim;
+    for (int b = 0; b < batch_size; ++b)
+        for (int h = 0; h < heads; ++h) {
+            int cnt = cnts[b * heads + h];
+            for (int s = 0; s < seq_len; ++s) {
+                if (s / chunk_size < cnt) continue;
+                if (offset_start + s >= offset_end) continue;
+                long pid = position_ids[b * stride_pid_b + h * stride_pid_h + (s / chunk_size) * stride_pid_s];
+                const uint16_t *cs = cos_sin + (pid * chunk_size + s % chunk_size) * stride_cos_sin;
+                const uint16_t *xp = x + b * stride_xb + h * stride_xh + s * stride_xs;
+                uint16_t *op = output_cache + b * stride_ob + h * stride_oh + (long)(offset_start + s) * stride_os;
+                if (glm) rope_glm_row(xp, cs, op);
+                else rope_llama_row(xp, cs, op, half_dim);
+            }
+        }
+}
+
+/* apply_rotary_pos_emb_new (functions.h:240, rope_new.cu:55-122): plain NeoX
+ * RoPE with an int64 position per (b,h,s); output has x's strides. */
+ORACLE_API void oracle_rope_new(const uint16_t *x, const uint16_t *cos_sin,
+                                const int64_t *position_ids, uint16_t *output, int batch_size,
+                                int heads, int seq_len, int embed_dim, long stride_xb,
+                                long stride_xh, long stride_xs, long stride_cos_sin,
+                                long stride_pid_b, long stride_pid_h, long stride_pid_s,
+                                int half_dim) {
+    (void)embed_dim;
+    for (int b = 0; b < batch_size; ++b)
+        for (int h = 0; h < heads; ++h)
+            for (int s = 0; s < seq_len; ++s) {
+                long pid = (long)position_ids[b * stride_pid_b + h * stride_pid_h + s * stride_pid_s];
+                long xo = b * stride_xb + h * stride_xh + s * stride_xs;
+                rope_llama_row(x + xo, cos_sin + pid * stride_cos_sin, output + xo, half_dim);
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a11: sparse attention over the assembled buffers (models/base.py:341)     */
+/* ------------------------------------------------------------------------- */
+/* q [bs][q_heads][D] bf16 (q_len = 1), k/v [bs][kv_heads][kv_stride rows][D]
+ * bf16, first kv_len rows attended.  out [bs][q_heads][D] bf16 =
+ * softmax(q.K^T * scale) V in double precision, rounded once.  flash-attn is
+ * un-vendored: the device kernel is compared with this at rtol 1e-3 on f32
+ * outputs / 1 bf16 ulp (tests), not bit-exactly. */
+ORACLE_API void oracle_sparse_attention(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                        uint16_t *out, float *out_f32, int bs, int q_heads,
+                                        int kv_heads, int head_dim, int kv_len, long kv_stride_rows,
+                                        float scale) {
+    int G = q_heads / kv_heads;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < bs; ++b)
+        for (int qh = 0; qh < q_heads; ++qh) {
+            int h = qh / G;
+            const uint16_t *qp = q + ((size_t)b * q_heads + qh) * head_dim;
+            const uint16_t *kp = k + ((size_t)b * kv_heads + h) * (size_t)kv_stride_rows * head_dim;
+            const uint16_t *vp = v + ((size_t)b * kv_heads + h) * (size_t)kv_stride_rows * head_dim;
+            double *sc = (double *)malloc((size_t)kv_len * sizeof(double));
+            double mx = -1e300;
+            for (int j = 0; j < kv_len; ++j) {
+                double acc = 0;
+                for (int d = 0; d < head_dim; ++d)
+                    acc += (double)bf2f(qp[d]) * (double)bf2f(kp[(size_t)j * head_dim + d]);
+                sc[j] = acc * (double)scale;
+                if (sc[j] > mx) mx = sc[j];
+            }
+            double den = 0;
+            for (int j = 0; j < kv_len; ++j) { sc[j] = exp(sc[j] - mx); den += sc[j]; }
+            for (int d = 0; d < head_dim; ++d) {
+                double acc = 0;
+                for (int j = 0; j < kv_len; ++j) acc += sc[j] * (double)bf2f(vp[(size_t)j * head_dim + d]);
+                float r = (float)(acc / den);
+                if (out) out[((size_t)b * q_heads + qh) * head_dim + d] = f2bf(r);
+                if (out_f32) out_f32[((size_t)b * q_heads + qh) * head_dim + d] = r;
+            }
+            free(sc);
+        }
+}

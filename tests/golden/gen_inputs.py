@@ -1,0 +1,95 @@
+"""Seeded synthetic inputs shared by make_golden.py (fixture generator, runs only where
+/root/reference exists) and the tests (run anywhere).  Pure torch-CPU, no reference code.
+
+The fixtures under tests/golden/*.npz hold only what cannot be regenerated from the
+seed: tensors produced by the reference's own code (U/SV from its SVD, landmarks,
+selections, buffers).  Inputs are regenerated here from the seed.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+CASES = {
+    # name: model-shape + cache-shape parameters
+    "llama_small": dict(layers=1, q_heads=32, kv_heads=8, head_dim=128, L=2048, budget=256,
+                        chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=1234),
+    "llama_cpu_b1024": dict(layers=1, q_heads=32, kv_heads=8, head_dim=128, L=2200, budget=1024,
+                            chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=4321),
+    "glm_small": dict(layers=1, q_heads=32, kv_heads=2, head_dim=128, L=2048, budget=256,
+                      chunk=8, rank=160, rope_theta=10000.0, glm=True, seed=777),
+}
+
+
+def config_of(case):
+    c = CASES[case]
+    return SimpleNamespace(num_hidden_layers=c["layers"], num_attention_heads=c["q_heads"],
+                           num_key_value_heads=c["kv_heads"], hidden_size=c["q_heads"] * c["head_dim"])
+
+
+def cos_sin_cache(case, max_pos):
+    """Llama: [max_pos, 128] = cos[:64] | sin[:64] (models/llama.py:323-332 layout).
+    GLM: [max_pos, 64] = cos[:32] | sin[:32] (models/glm.py:261-273 layout)."""
+    c = CASES[case]
+    rot = 64 if c["glm"] else c["head_dim"]
+    inv_freq = 1.0 / (c["rope_theta"] ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)  # [max_pos, rot/2]
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.bfloat16).contiguous()
+
+
+def make_inputs(case):
+    """Returns dict(k_pre [1,kv,L,D] bf16 pre-RoPE (approximately rank-`rank`), v [1,kv,L,D],
+    q_last [1,q_heads,1,D], q_steps [steps,1,q_heads,1,D], cos_sin)."""
+    c = CASES[case]
+    g = torch.Generator().manual_seed(c["seed"])
+    L, kv, D, r = c["L"], c["kv_heads"], c["head_dim"], c["rank"]
+    a = torch.randn(L, r, generator=g)
+    b = torch.randn(r, kv * D, generator=g) / math.sqrt(r)
+    k = a @ b + 0.05 * torch.randn(L, kv * D, generator=g)
+    k_pre = k.view(1, L, kv, D).transpose(1, 2).contiguous().to(torch.bfloat16)
+    v = torch.randn(1, kv, L, D, generator=g).to(torch.bfloat16)
+    q_last = (torch.randn(1, c["q_heads"], 1, D, generator=g) * 2.0).to(torch.bfloat16)
+    steps = 4
+    q_steps = []
+    qf = q_last.float()
+    for _ in range(steps):
+        qf = qf + 0.5 * torch.randn(qf.shape, generator=g)
+        q_steps.append(qf.to(torch.bfloat16))
+    return dict(k_pre=k_pre, v=v, q_last=q_last, q_steps=torch.stack(q_steps),
+                cos_sin=cos_sin_cache(case, L + 1024))
+
+
+def rope_neox_torch(x, cos_sin, position_ids):
+    """bf16 tensor-op RoPE exactly as the reference's pure-torch helpers compute it
+    (models/tensor_op.py:127-151): (x*cos) + (rotate_half(x)*sin), every op rounding to bf16.
+    x [b,h,s,D]; position_ids [b,h,s] or [b,s]; cos_sin [P, D] = cos[:D/2] | sin[:D/2]."""
+    half = cos_sin.shape[-1] // 2
+    cos = torch.cat((cos_sin[:, :half], cos_sin[:, :half]), dim=-1)
+    sin = torch.cat((cos_sin[:, half:], cos_sin[:, half:]), dim=-1)
+    if position_ids.dim() == 2:
+        position_ids = position_ids.unsqueeze(1).expand(-1, x.shape[1], -1)
+    c = cos[position_ids]
+    s = sin[position_ids]
+    x1, x2 = x[..., :half], x[..., half:]
+    rot = torch.cat((-x2, x1), dim=-1)
+    return (x * c) + (rot * s)
+
+
+def rope_glm_torch(x, cos_sin, position_ids):
+    """GLM-4 interleaved half-dim RoPE in bf16 tensor ops: pairs (2t,2t+1), t<32 use
+    cos_sin[pos, t], cos_sin[pos, t+32]; dims 64..127 pass through (models/glm.py:430-469)."""
+    if position_ids.dim() == 2:
+        position_ids = position_ids.unsqueeze(1).expand(-1, x.shape[1], -1)
+    cs = cos_sin[position_ids]  # [b,h,s,64]
+    c, s = cs[..., :32], cs[..., 32:]
+    x_rot, x_pass = x[..., :64], x[..., 64:]
+    xe, xo = x_rot[..., 0::2], x_rot[..., 1::2]
+    oe = (xe * c) + ((-xo) * s)
+    oo = (xo * c) + (xe * s)
+    out_rot = torch.stack((oe, oo), dim=-1).flatten(-2)
+    return torch.cat((out_rot, x_pass), dim=-1)
+
+
+def rope_torch(case, x, cos_sin, position_ids):
+    return rope_glm_torch(x, cos_sin, position_ids) if CASES[case]["glm"] else rope_neox_torch(x, cos_sin, position_ids)
