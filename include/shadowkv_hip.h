@@ -1,0 +1,188 @@
+/*
+ * shadowkv_hip.h -- C ABI of libshadowkv_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the native half of the ShadowKV decode path.  Part 1 exports one
+ * launcher per function of the reference's pybind11 module `kernels.shadowkv`
+ * (/root/reference/kernels/main.cu:42-81, prototypes /root/reference/kernels/functions.h:71-463):
+ * same argument order and meaning, torch::Tensor replaced by a raw pointer, plus an explicit
+ * stream as the last argument (the reference launches on the legacy default stream, except
+ * gather_copy_with_offsets which uses the current stream; here the caller always says which).
+ * Part 2 exports the fused launchers the decode path actually uses on MI355X (what
+ * ShadowKVCache_CPU.get_retrieval_position_ids / get_value_cache / get_key_cache and the
+ * attention call of LLM.layer_compute bind to).
+ *
+ * Conventions: all device pointers; bf16 tensors are `void*`; every tensor contiguous unless
+ * strides are passed (strides / lengths in ELEMENTS, as in the reference); `stream` is a
+ * hipStream_t (NULL = default stream).  Every function returns 0 on success, <0 on an argument
+ * / support error (SKV_ERR_*), and never throws; launches are asynchronous.  Nothing is
+ * allocated inside a launcher (graph-capturable), workspaces are passed in.
+ */
+#ifndef SHADOWKV_HIP_H
+#define SHADOWKV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKV_OK 0
+#define SKV_ERR_ARG (-1)         /* inconsistent sizes / misaligned strides */
+#define SKV_ERR_UNSUPPORTED (-2) /* shape outside what the gfx950 kernels are built for */
+#define SKV_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch */
+
+#if defined(__GNUC__)
+#define SKV_EXPORT __attribute__((visibility("default")))
+#else
+#define SKV_EXPORT
+#endif
+
+typedef void* skv_stream_t;
+
+/* library / device info; returns the compiled ABI version (1) */
+SKV_EXPORT int skv_abi_version(void);
+/* text of the last HIP error seen by a launcher on this thread ("" if none) */
+SKV_EXPORT const char* skv_last_error(void);
+/* 1 if a row-mover spin ever timed out on the current device (results then invalid) */
+SKV_EXPORT int skv_move_timeout_flag(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1: the `kernels.shadowkv` surface (functions.h line cited per entry)
+ * ---------------------------------------------------------------------------------------- */
+
+/* functions.h:460  batch_gemm_softmax(A, B, D, Norm, Sum, Softmax, batch_count, m, n, k, alpha, beta)
+ * A [batch][m][k], B [batch][n][k], D/Softmax [batch][m][n] bf16; Norm/Sum [batch][ceil(n/256)][m] f32.
+ * k must be 128, m in {1,2,4,8,16}.  beta ignored (as in the reference, OnlyAlphaScaling). */
+SKV_EXPORT int skv_batch_gemm_softmax(const void* A, const void* B, void* D, float* Norm, float* Sum, void* Softmax,
+                           int batch_count, int m, int n, int k, float alpha, float beta, skv_stream_t stream);
+
+/* functions.h:123  reorder_keys_and_compute_offsets(cached_pos_ids, cur_pos_ids, offsets, cnts, bs, heads, map_size)
+ * any 1 <= map_size <= 1024 (the reference silently does nothing unless 128/256/512/1024). */
+SKV_EXPORT int skv_reorder_keys_and_compute_offsets(int64_t* cached_pos_ids, const int64_t* cur_pos_ids, int32_t* offsets,
+                                         int32_t* cnts, int batch_size, int heads, int map_size,
+                                         skv_stream_t stream);
+
+/* functions.h:151  gather_copy_with_offsets(values, v_cache_buffer, temp, offsets, cnts, signals, ...)
+ * `values` is pinned, device-mapped host memory.  `temp` is accepted and unused (no bounce buffer).
+ * `signals` uint32[batch*heads], zero on entry, zero again on completion. */
+SKV_EXPORT int skv_gather_copy_with_offsets(const void* values, void* v_cache_buffer, void* temp, const int32_t* offsets,
+                                 const int32_t* cnts, uint32_t* signals, int batch_size, int heads,
+                                 int cpu_v_length, int gpu_v_length, int gpu_v_offset, int gpu_v_stride,
+                                 int map_size, skv_stream_t stream);
+
+/* functions.h:97  gather_copy_d2d_with_offsets(keys, offsets, cnts, bs, heads, gpu_k_length, gpu_k_offset,
+ * gpu_k_stride, map_size).  Extra argument `signals` (same contract as above): the reference serialises a
+ * (batch, head) inside one CTA, this library spreads it over a team of workgroups. */
+SKV_EXPORT int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, uint32_t* signals,
+                                     int batch_size, int heads, int gpu_k_length, int gpu_k_offset,
+                                     int gpu_k_stride, int map_size, skv_stream_t stream);
+
+/* functions.h:71  gather_copy(values, v_cache_buffer, position_ids(int64), bs, heads, cpu_v_length, gpu_v_length, map_size) */
+SKV_EXPORT int skv_gather_copy(const void* values, void* v_cache_buffer, const int64_t* position_ids, int batch_size,
+                    int heads, int cpu_v_length, int gpu_v_length, int map_size, skv_stream_t stream);
+
+/* functions.h:431  batch_gather_gemm(a=U, b=SV, cos, sin, position_ids(int32), output, bs, heads, seq_len,
+ * embed_dim, rank, sparse_budget, max_seq_len, chunk_size, offset_array=cnts).  cos / sin are unused by the
+ * reference too (its fused epilogue is disabled).  Writes pre-RoPE bf16 rows >= cnt*chunk_size. */
+SKV_EXPORT int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const void* sin,
+                          const int32_t* position_ids, void* output, int batch_size, int heads, int seq_len,
+                          int embed_dim, int rank, int sparse_budget, int max_seq_len, int chunk_size,
+                          const int32_t* offset_array, skv_stream_t stream);
+
+/* functions.h:362 / :396  apply_rotary_pos_emb_push_cache_opt[_glm] and :328 apply_rotary_pos_emb_push_cache
+ * (same semantics as _opt). */
+SKV_EXPORT int skv_apply_rotary_pos_emb_push_cache_opt(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                            void* output_cache, const int32_t* cnts, int batch_size, int heads,
+                                            int seq_len, int embed_dim, int stride_xb, int stride_xh,
+                                            int stride_xs, int stride_xe, int stride_cos_sin, int stride_pid_b,
+                                            int stride_pid_h, int stride_pid_s, int stride_output_b,
+                                            int stride_output_h, int stride_output_s, int offset_output_s_start,
+                                            int offset_output_s_end, int half_dim, int chunk_size,
+                                            skv_stream_t stream);
+SKV_EXPORT int skv_apply_rotary_pos_emb_push_cache_opt_glm(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                                void* output_cache, const int32_t* cnts, int batch_size,
+                                                int heads, int seq_len, int embed_dim, int stride_xb,
+                                                int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                                int stride_pid_b, int stride_pid_h, int stride_pid_s,
+                                                int stride_output_b, int stride_output_h, int stride_output_s,
+                                                int offset_output_s_start, int offset_output_s_end, int half_dim,
+                                                int chunk_size, skv_stream_t stream);
+SKV_EXPORT int skv_apply_rotary_pos_emb_push_cache(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                        void* output_cache, const int32_t* cnts, int batch_size, int heads,
+                                        int seq_len, int embed_dim, int stride_xb, int stride_xh, int stride_xs,
+                                        int stride_xe, int stride_cos_sin, int stride_pid_b, int stride_pid_h,
+                                        int stride_pid_s, int stride_output_b, int stride_output_h,
+                                        int stride_output_s, int offset_output_s_start, int offset_output_s_end,
+                                        int half_dim, int chunk_size, skv_stream_t stream);
+
+/* functions.h:240  apply_rotary_pos_emb_new(x, cos_sin, position_ids(int64), output, ...) */
+SKV_EXPORT int skv_apply_rotary_pos_emb_new(const void* x, const void* cos_sin, const int64_t* position_ids, void* output,
+                                 int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                                 int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                 int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                                 skv_stream_t stream);
+
+/* functions.h:281  apply_rotary_pos_emb_new_v2(x, cos_sin, position_ids(int32 chunk ids), output, ..., chunk_size) */
+SKV_EXPORT int skv_apply_rotary_pos_emb_new_v2(const void* x, const void* cos_sin, const int32_t* position_ids, void* output,
+                                    int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                                    int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                    int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                                    int chunk_size, skv_stream_t stream);
+
+/* functions.h:187  apply_rotary_pos_emb(x, cos, sin, position_ids(int64), output, ...) separate full-width tables */
+SKV_EXPORT int skv_apply_rotary_pos_emb(const void* x, const void* cos, const void* sin, const int64_t* position_ids,
+                             void* output, int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                             int stride_xh, int stride_xs, int stride_xe, int stride_cos, int stride_sin,
+                             int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                             skv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2: fused decode-path launchers (what the MI355X host code calls)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch skv_select_chunks needs for (blocks = bs*kv_heads, groups, n_landmarks). */
+SKV_EXPORT size_t skv_select_workspace_bytes(int blocks, int groups, int n_landmarks);
+
+/* One call = ShadowKVCache_CPU.get_retrieval_position_ids (/root/reference/models/kv_cache.py:983-1057):
+ * score q against the landmarks, softmax, max over the GQA group, exact top-`select_sets`
+ * (ties -> lowest landmark slot), slot -> chunk id through k_landmark_idx, diff against the
+ * resident set.  q [blocks][groups][128] bf16 (q_len == 1), landmarks [blocks][n][128] bf16,
+ * landmark_idx int64 [blocks][n], cached_pos_ids int64 [blocks][select_sets] (in/out),
+ * offsets int32 [blocks][select_sets], cnts int32 [blocks].  Optional outputs (may be NULL):
+ * softmax_out bf16 [blocks][groups][n], selected_out int64 [blocks][select_sets]. */
+SKV_EXPORT int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                      int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
+                      int blocks, int groups, int n_landmarks, int select_sets, float alpha, skv_stream_t stream);
+
+/* ShadowKVCache_CPU.get_value_cache (kv_cache.py:1059-1106): compaction of hit chunks + fetch of miss
+ * chunks from the pinned host table into the sparse region.  Strides / offsets in bf16 elements.
+ * host_values == NULL: compaction only (this is also the K-side compaction of get_key_cache,
+ * kv_cache.py:1140-1150). */
+SKV_EXPORT int skv_move_chunks(const void* host_values, void* cache_buffer, const int32_t* offsets, const int32_t* cnts,
+                    uint32_t* signals, long long host_block_stride, long long cache_block_stride,
+                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream);
+
+/* ShadowKVCache_CPU.get_key_cache, rebuild part (kv_cache.py:1157-1168 -> models/tensor_op.py:201-238):
+ * k_cache[b][h][sparse_start + i][:] = RoPE(bf16(U[b][pos(i)] . SV[b][h]^T), pos(i)) for chunks >= cnts.
+ * chunk_ids int64 [bs][heads][select_sets] (the reordered cached_pos_ids); rope_mode 1 = Llama
+ * (cos_sin width 128), 2 = GLM (width 64).  Cache strides in elements. */
+SKV_EXPORT int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,
+                     const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
+                     int rank, int select_sets, int chunk_size, long long cos_sin_stride,
+                     long long cache_stride_b, long long cache_stride_h, long long cache_stride_s,
+                     int sparse_start, int rope_mode, skv_stream_t stream);
+
+/* Sparse decode attention (replaces flash_attn_with_kvcache at /root/reference/models/base.py:341 for
+ * q_len == 1).  q [bs][q_heads][128], k/v [bs][kv_heads][rows][128] (kv_head_stride elements between heads),
+ * out [bs][q_heads][128] bf16.  kv_len_dev (int32 on device) overrides kv_len when non-NULL.
+ * workspace: skv_attn_workspace_bytes(bs, q_heads, splits). */
+SKV_EXPORT size_t skv_attn_workspace_bytes(int batch_size, int q_heads, int splits);
+SKV_EXPORT int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,
+                         const int32_t* kv_len_dev, int kv_len, long long kv_head_stride, int batch_size,
+                         int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHADOWKV_HIP_H */

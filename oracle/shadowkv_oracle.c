@@ -123,24 +123,48 @@ static inline uint64_t exp_to_fixed(float e) {
 /* batch_gemm_softmax (kernels/functions.h:460, kernels/batch_gemm_softmax.cu:229-293,
  * kernels/batch_gemm_softmax.h:207-302, :523-614).
  *   A [batch][m][k] bf16 row-major (q), B [batch][n][k] bf16 (landmarks),
- *   D, Softmax [batch][m][n] bf16, Norm / Sum [batch][m][ceil(n/256)] f32.
- * Restated arithmetic:
- *   D = bf16(alpha * dot)                      (f32 mul, one bf16 rounding)
- *   mx = max_j float(D_j)                       (exact)
- *   S  = sum_j trunc(2^36 * exp(float(D_j)-mx)) (integer, order-free)
- *   inv = 1 / (float)(S * 2^-36)
- *   P_j = bf16(exp(float(D_j)-mx) * inv)
- * Norm[b*m*nblk + row] <- mx, Sum[b*m*nblk + row] <- inv  (partials are laid
- * out [batch][tile][m], ldn = m, batch stride nblk*m: batch_gemm_softmax.cu
- * :249-271; the final values land in tile 0's slots, the only entries the third
- * kernel reads back, batch_gemm_softmax.h:274-275); other entries are left alone.
+ *   D, Softmax [batch][m][n] bf16, Norm / Sum [batch][T][m] f32, T = ceil(n/256)
+ *   (ldn = lds = m, batch stride T*m: batch_gemm_softmax.cu:249-271).
+ * Same three stages as the reference (GEMM + per-256-column-tile partials, final
+ * reduction, apply), with every f32 operation order written out:
+ *  1. D_j   = bf16(alpha * dot_j)                       f32 mul, one bf16 rounding
+ *     per tile t (columns 256t..256t+255):
+ *       m_t = max_j float(D_j)                           exact
+ *       S_t = sum_j trunc(2^36 * exp(float(D_j) - m_t))  integer, order-free
+ *       s_t = (float)(S_t * 2^-36)                       one rounding
+ *     Norm[b][t][row] = m_t, Sum[b][t][row] = s_t        (CUTLASS EpilogueVisitorSoftmax
+ *     takes max/sum over the bf16-rounded D; un-vendored, see header)
+ *  2. m = max_t m_t;  w_t = s_t * exp(m_t - m);
+ *     s = lane-strided sum: lane l (0..63) adds w_l, w_{l+64}, ... in order starting
+ *     from 0, then a balanced binary tree over the 64 lanes in natural order;
+ *     inv = 1/s;  Norm[b][0][row] <- m, Sum[b][0][row] <- inv (tile-0 slots are what
+ *     the apply stage reads back, batch_gemm_softmax.h:274-275)
+ *  3. P_j = bf16(exp(float(D_j) - m) * inv)              batch_gemm_softmax.h:289-292
  * beta is ignored (ScaleType::OnlyAlphaScaling, batch_gemm_softmax.cu:157-163). */
+static void softmax_finalize(const float *mt, const float *st, int T, int stride, float *m_out,
+                             float *inv_out) {
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t)
+        if (mt[(size_t)t * stride] > m) m = mt[(size_t)t * stride];
+    float lane[64];
+    for (int l = 0; l < 64; ++l) {
+        float acc = 0.0f;
+        for (int t = l; t < T; t += 64)
+            acc = acc + st[(size_t)t * stride] * spec_exp(mt[(size_t)t * stride] - m);
+        lane[l] = acc;
+    }
+    for (int w = 64; w > 1; w >>= 1)
+        for (int i = 0; i < w / 2; ++i) lane[i] = lane[2 * i] + lane[2 * i + 1];
+    *m_out = m;
+    *inv_out = 1.0f / lane[0];
+}
+
 ORACLE_API void oracle_batch_gemm_softmax(const uint16_t *A, const uint16_t *B, uint16_t *D,
                                           float *Norm, float *Sum, uint16_t *Softmax,
                                           int batch_count, int m, int n, int k, float alpha,
                                           float beta) {
     (void)beta;
-    int nblk = (n + 255) / 256;
+    int T = (n + 255) / 256;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < batch_count; ++b) {
         for (int r = 0; r < m; ++r) {
@@ -148,21 +172,26 @@ ORACLE_API void oracle_batch_gemm_softmax(const uint16_t *A, const uint16_t *B, 
             const uint16_t *Bb = B + (size_t)b * n * k;
             uint16_t *Dr = D + ((size_t)b * m + r) * n;
             uint16_t *Pr = Softmax + ((size_t)b * m + r) * n;
-            float mx = -INFINITY;
-            for (int j = 0; j < n; ++j) {
-                float v = alpha * score_dot(q, Bb + (size_t)j * k, k);
-                uint16_t d = f2bf(v);
-                Dr[j] = d;
-                float fd = bf2f(d);
-                if (fd > mx) mx = fd;
+            float *mt = Norm + (size_t)b * T * m + r; /* [t*m] */
+            float *st = Sum + (size_t)b * T * m + r;
+            for (int t = 0; t < T; ++t) {
+                int j0 = t * 256, j1 = j0 + 256 < n ? j0 + 256 : n;
+                float mx = -INFINITY;
+                for (int j = j0; j < j1; ++j) {
+                    uint16_t d = f2bf(alpha * score_dot(q, Bb + (size_t)j * k, k));
+                    Dr[j] = d;
+                    if (bf2f(d) > mx) mx = bf2f(d);
+                }
+                uint64_t S = 0;
+                for (int j = j0; j < j1; ++j) S += exp_to_fixed(spec_exp(bf2f(Dr[j]) - mx));
+                mt[(size_t)t * m] = mx;
+                st[(size_t)t * m] = (float)((double)S * (1.0 / 68719476736.0));
             }
-            uint64_t S = 0;
-            for (int j = 0; j < n; ++j) S += exp_to_fixed(spec_exp(bf2f(Dr[j]) - mx));
-            float s = (float)((double)S * (1.0 / 68719476736.0));
-            float inv = 1.0f / s;
-            for (int j = 0; j < n; ++j) Pr[j] = f2bf(spec_exp(bf2f(Dr[j]) - mx) * inv);
-            if (Norm) Norm[(size_t)b * m * nblk + r] = mx;
-            if (Sum) Sum[(size_t)b * m * nblk + r] = inv;
+            float mfin, inv;
+            softmax_finalize(mt, st, T, m, &mfin, &inv);
+            for (int j = 0; j < n; ++j) Pr[j] = f2bf(spec_exp(bf2f(Dr[j]) - mfin) * inv);
+            mt[0] = mfin;
+            st[0] = inv;
         }
     }
 }
@@ -233,8 +262,9 @@ ORACLE_API int oracle_group_max_topk(const uint16_t *P, const int64_t *landmark_
  * Duplicate ids in `cached`: the reference's hash insert is racy; here the
  * LOWEST slot wins, as in the golden model (std::map::insert keeps the first,
  * test_cached_gather_copy.cu:83-87).  Ids are truncated to int32 like
- * map.cuh:771,776.  Unlike the reference (silent no-op, gather_copy.cu:278-306)
- * any map_size >= 1 is accepted. */
+ * map.cuh:771,776.  Negative ids (the -1 "empty" sentinel position_ids start with,
+ * kv_cache.py:634) never match.  Unlike the reference (silent no-op,
+ * gather_copy.cu:278-306) any map_size >= 1 is accepted. */
 typedef struct { int32_t off; int32_t key; } ok_pair;
 static int cmp_pair_off(const void *a, const void *b) {
     const ok_pair *x = (const ok_pair *)a, *y = (const ok_pair *)b;
@@ -260,8 +290,9 @@ ORACLE_API void oracle_reorder_keys_and_compute_offsets(int64_t *cached_pos_ids,
         for (int i = 0; i < map_size; ++i) {
             int32_t key = (int32_t)cur[i];
             int slot = -1;
-            for (int s = 0; s < map_size; ++s)
-                if ((int32_t)old[s] == key) { slot = s; break; }
+            if (key >= 0)
+                for (int s = 0; s < map_size; ++s)
+                    if ((int32_t)old[s] == key) { slot = s; break; }
             if (slot >= 0) { hits[nh].off = slot; hits[nh].key = key; ++nh; }
             else miss[nm++] = key;
         }

@@ -1,0 +1,89 @@
+"""ctypes binding of libshadowkv_hip.so (C ABI: include/shadowkv_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at
+first use, loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C shadowkv_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshadowkv_hip.so")
+
+_lib = None
+
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+_ROPE_PUSH = [c_p] * 5 + [c_int] * 19 + [c_p]
+
+_SIGS = {
+    "skv_abi_version": (c_int, []),
+    "skv_last_error": (ctypes.c_char_p, []),
+    "skv_move_timeout_flag": (c_int, []),
+    "skv_batch_gemm_softmax": (c_int, [c_p] * 6 + [c_int] * 4 + [c_f, c_f, c_p]),
+    "skv_reorder_keys_and_compute_offsets": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),
+    "skv_gather_copy_with_offsets": (c_int, [c_p] * 6 + [c_int] * 7 + [c_p]),
+    "skv_gather_copy_d2d_with_offsets": (c_int, [c_p] * 4 + [c_int] * 6 + [c_p]),
+    "skv_gather_copy": (c_int, [c_p] * 3 + [c_int] * 5 + [c_p]),
+    "skv_batch_gather_gemm": (c_int, [c_p] * 6 + [c_int] * 8 + [c_p, c_p]),
+    "skv_apply_rotary_pos_emb_push_cache_opt": (c_int, _ROPE_PUSH),
+    "skv_apply_rotary_pos_emb_push_cache_opt_glm": (c_int, _ROPE_PUSH),
+    "skv_apply_rotary_pos_emb_push_cache": (c_int, _ROPE_PUSH),
+    "skv_apply_rotary_pos_emb_new": (c_int, [c_p] * 4 + [c_int] * 13 + [c_p]),
+    "skv_apply_rotary_pos_emb_new_v2": (c_int, [c_p] * 4 + [c_int] * 14 + [c_p]),
+    "skv_apply_rotary_pos_emb": (c_int, [c_p] * 5 + [c_int] * 14 + [c_p]),
+    "skv_select_workspace_bytes": (c_sz, [c_int] * 3),
+    "skv_select_chunks": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f, c_p]),
+    "skv_move_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
+    "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p]),
+    "skv_attn_workspace_bytes": (c_sz, [c_int] * 3),
+    "skv_sparse_attention": (c_int, [c_p] * 6 + [c_int, c_ll] + [c_int] * 5 + [c_f, c_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class ShadowKVNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ShadowKVNativeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build() or `make -C shadowkv_amd/csrc`). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.skv_abi_version() != 1:
+            raise ShadowKVNativeError("libshadowkv_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: "invalid argument (sizes / alignment)", -2: "shape not supported by the gfx950 kernels",
+        -3: "kernel launch failed"}
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = lib().skv_last_error().decode() if rc == -3 else ""
+        raise ShadowKVNativeError(f"{what}: {_ERR.get(rc, rc)} {detail}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

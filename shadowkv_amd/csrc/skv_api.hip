@@ -1,0 +1,269 @@
+// extern "C" surface of libshadowkv_hip.so (declared in include/shadowkv_hip.h).
+// Thin argument checking + dispatch to the launchers in skv_select / skv_move / skv_rebuild /
+// skv_attn / skv_rope.  No allocation, no synchronisation: every entry point is graph-capturable.
+#include "../../include/shadowkv_hip.h"
+#include "skv_common.h"
+
+#include <string.h>
+
+// launchers (defined in the kernel files)
+int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
+                     float alpha, hipStream_t st);
+int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void* P, int B, int m, int N,
+                                   hipStream_t st);
+int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score, int B,
+                                  int G, int N, hipStream_t st);
+int skv_launch_topk_reorder(const void* score, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
+                            int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S, hipStream_t st);
+int skv_launch_move_rows(const void* host_rows, void* dev, const int32_t* offsets, const int32_t* cnts,
+                         unsigned int* signals, long long host_len_elems, long long dev_stride_elems,
+                         long long dev_off_elems, int B, int S, hipStream_t st);
+int skv_launch_gather_rows(const void* host_rows, void* dev, const int64_t* ids, long long host_len_elems,
+                           long long dev_len_elems, int B, int S, hipStream_t st);
+int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
+                       const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
+                       int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
+                       long long out_stride_s, int out_row0, int mode, hipStream_t st);
+int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
+                                const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
+                                int Hkv, int head_dim, int splits, float scale, hipStream_t st);
+int skv_launch_rope_chunked(const void* x, const void* cos_sin, const int32_t* pid, void* out, const int32_t* cnts,
+                            int batch, int heads, int seq_len, int embed_dim, long long sxb, long long sxh,
+                            long long sxs, long long sxe, long long scs, long long spb, long long sph, long long sps,
+                            long long sob, long long soh, long long sos, int off_start, int off_end, int half_dim,
+                            int chunk, int glm, int mode, hipStream_t st);
+int skv_launch_rope_plain(const void* x, const void* cos_sin, const void* sin, long long ssin, const int64_t* pid,
+                          void* out, int batch, int heads, int seq_len, int embed_dim, long long sxb, long long sxh,
+                          long long sxs, long long sxe, long long scs, long long spb, long long sph, long long sps,
+                          int half_dim, hipStream_t st);
+
+static thread_local char g_err[256] = "";
+
+static int finish(int rc) {
+    if (rc != SKV_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        strncpy(g_err, hipGetErrorString(e), sizeof(g_err) - 1);
+        return SKV_ERR_LAUNCH;
+    }
+    return SKV_OK;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct SelectWs {
+    void* D;
+    float* pmax;
+    float* psum;
+    void* score;
+    size_t total;
+};
+static SelectWs carve_select_ws(void* base, int blocks, int groups, int n) {
+    const size_t T = (size_t)(n + 255) / 256;
+    SelectWs w;
+    size_t off = 0;
+    unsigned char* p = (unsigned char*)base;
+    w.D = p + off;
+    off += align256((size_t)blocks * groups * n * 2);
+    w.pmax = (float*)(p + off);
+    off += align256((size_t)blocks * T * groups * 4);
+    w.psum = (float*)(p + off);
+    off += align256((size_t)blocks * T * groups * 4);
+    w.score = p + off;
+    off += align256((size_t)blocks * n * 2);
+    w.total = off;
+    return w;
+}
+
+extern "C" {
+
+int skv_abi_version(void) { return 1; }
+const char* skv_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- part 1: legacy surface
+int skv_batch_gemm_softmax(const void* A, const void* B, void* D, float* Norm, float* Sum, void* Softmax,
+                           int batch_count, int m, int n, int k, float alpha, float beta, skv_stream_t stream) {
+    (void)beta;
+    if (!A || !B || !D || !Norm || !Sum || !Softmax || batch_count < 1 || n < 1) return SKV_ERR_ARG;
+    if (k != 128) return SKV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = skv_launch_score(A, B, D, Norm, Sum, batch_count, m, n, alpha, st);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_softmax_final_apply(D, Norm, Sum, Softmax, batch_count, m, n, st));
+}
+
+int skv_reorder_keys_and_compute_offsets(int64_t* cached_pos_ids, const int64_t* cur_pos_ids, int32_t* offsets,
+                                         int32_t* cnts, int batch_size, int heads, int map_size,
+                                         skv_stream_t stream) {
+    if (!cached_pos_ids || !cur_pos_ids || !offsets || !cnts || batch_size * heads < 1) return SKV_ERR_ARG;
+    return finish(skv_launch_topk_reorder(nullptr, nullptr, cur_pos_ids, cached_pos_ids, offsets, cnts, nullptr,
+                                          batch_size * heads, 0, map_size, (hipStream_t)stream));
+}
+
+int skv_gather_copy_with_offsets(const void* values, void* v_cache_buffer, void* temp, const int32_t* offsets,
+                                 const int32_t* cnts, uint32_t* signals, int batch_size, int heads,
+                                 int cpu_v_length, int gpu_v_length, int gpu_v_offset, int gpu_v_stride,
+                                 int map_size, skv_stream_t stream) {
+    (void)temp;
+    (void)gpu_v_length;
+    if (!values || !v_cache_buffer || !offsets || !cnts || !signals) return SKV_ERR_ARG;
+    return finish(skv_launch_move_rows(values, v_cache_buffer, offsets, cnts, signals, cpu_v_length, gpu_v_stride,
+                                       gpu_v_offset, batch_size * heads, map_size, (hipStream_t)stream));
+}
+
+int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, uint32_t* signals,
+                                     int batch_size, int heads, int gpu_k_length, int gpu_k_offset,
+                                     int gpu_k_stride, int map_size, skv_stream_t stream) {
+    (void)gpu_k_length;
+    if (!keys || !offsets || !cnts || !signals) return SKV_ERR_ARG;
+    return finish(skv_launch_move_rows(nullptr, keys, offsets, cnts, signals, 0, gpu_k_stride, gpu_k_offset,
+                                       batch_size * heads, map_size, (hipStream_t)stream));
+}
+
+int skv_gather_copy(const void* values, void* v_cache_buffer, const int64_t* position_ids, int batch_size,
+                    int heads, int cpu_v_length, int gpu_v_length, int map_size, skv_stream_t stream) {
+    if (!values || !v_cache_buffer || !position_ids) return SKV_ERR_ARG;
+    return finish(skv_launch_gather_rows(values, v_cache_buffer, position_ids, cpu_v_length, gpu_v_length,
+                                         batch_size * heads, map_size, (hipStream_t)stream));
+}
+
+int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const void* sin,
+                          const int32_t* position_ids, void* output, int batch_size, int heads, int seq_len,
+                          int embed_dim, int rank, int sparse_budget, int max_seq_len, int chunk_size,
+                          const int32_t* offset_array, skv_stream_t stream) {
+    (void)cos;
+    (void)sin;
+    (void)max_seq_len;
+    if (!a || !b || !position_ids || !output || chunk_size < 1 || sparse_budget % chunk_size) return SKV_ERR_ARG;
+    return finish(skv_launch_rebuild(a, b, nullptr, position_ids, 0, offset_array, output, batch_size, heads,
+                                     seq_len, embed_dim, rank, sparse_budget / chunk_size, chunk_size, 0,
+                                     (long long)heads * sparse_budget * embed_dim,
+                                     (long long)sparse_budget * embed_dim, embed_dim, 0, 0, (hipStream_t)stream));
+}
+
+#define SKV_ROPE_PUSH_ARGS                                                                                       \
+    x, cos_sin, position_ids, output_cache, cnts, batch_size, heads, seq_len, embed_dim, stride_xb, stride_xh,   \
+        stride_xs, stride_xe, stride_cos_sin, stride_pid_b, stride_pid_h, stride_pid_s, stride_output_b,         \
+        stride_output_h, stride_output_s, offset_output_s_start, offset_output_s_end, half_dim, chunk_size
+
+int skv_apply_rotary_pos_emb_push_cache_opt(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                            void* output_cache, const int32_t* cnts, int batch_size, int heads,
+                                            int seq_len, int embed_dim, int stride_xb, int stride_xh,
+                                            int stride_xs, int stride_xe, int stride_cos_sin, int stride_pid_b,
+                                            int stride_pid_h, int stride_pid_s, int stride_output_b,
+                                            int stride_output_h, int stride_output_s, int offset_output_s_start,
+                                            int offset_output_s_end, int half_dim, int chunk_size,
+                                            skv_stream_t stream) {
+    if (!x || !cos_sin || !position_ids || !output_cache || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_chunked(SKV_ROPE_PUSH_ARGS, 0, 1, (hipStream_t)stream));
+}
+
+int skv_apply_rotary_pos_emb_push_cache_opt_glm(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                                void* output_cache, const int32_t* cnts, int batch_size,
+                                                int heads, int seq_len, int embed_dim, int stride_xb,
+                                                int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                                int stride_pid_b, int stride_pid_h, int stride_pid_s,
+                                                int stride_output_b, int stride_output_h, int stride_output_s,
+                                                int offset_output_s_start, int offset_output_s_end, int half_dim,
+                                                int chunk_size, skv_stream_t stream) {
+    if (!x || !cos_sin || !position_ids || !output_cache || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_chunked(SKV_ROPE_PUSH_ARGS, 1, 1, (hipStream_t)stream));
+}
+
+int skv_apply_rotary_pos_emb_push_cache(const void* x, const void* cos_sin, const int32_t* position_ids,
+                                        void* output_cache, const int32_t* cnts, int batch_size, int heads,
+                                        int seq_len, int embed_dim, int stride_xb, int stride_xh, int stride_xs,
+                                        int stride_xe, int stride_cos_sin, int stride_pid_b, int stride_pid_h,
+                                        int stride_pid_s, int stride_output_b, int stride_output_h,
+                                        int stride_output_s, int offset_output_s_start, int offset_output_s_end,
+                                        int half_dim, int chunk_size, skv_stream_t stream) {
+    if (!x || !cos_sin || !position_ids || !output_cache || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_chunked(SKV_ROPE_PUSH_ARGS, 0, 1, (hipStream_t)stream));
+}
+
+int skv_apply_rotary_pos_emb_new(const void* x, const void* cos_sin, const int64_t* position_ids, void* output,
+                                 int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                                 int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                 int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                                 skv_stream_t stream) {
+    if (!x || !cos_sin || !position_ids || !output) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_plain(x, cos_sin, nullptr, 0, position_ids, output, batch_size, heads, seq_len,
+                                        embed_dim, stride_xb, stride_xh, stride_xs, stride_xe, stride_cos_sin,
+                                        stride_pid_b, stride_pid_h, stride_pid_s, half_dim, (hipStream_t)stream));
+}
+
+int skv_apply_rotary_pos_emb_new_v2(const void* x, const void* cos_sin, const int32_t* position_ids, void* output,
+                                    int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                                    int stride_xh, int stride_xs, int stride_xe, int stride_cos_sin,
+                                    int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                                    int chunk_size, skv_stream_t stream) {
+    if (!x || !cos_sin || !position_ids || !output) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_chunked(x, cos_sin, position_ids, output, nullptr, batch_size, heads, seq_len,
+                                          embed_dim, stride_xb, stride_xh, stride_xs, stride_xe, stride_cos_sin,
+                                          stride_pid_b, stride_pid_h, stride_pid_s, 0, 0, 0, 0, 0, half_dim,
+                                          chunk_size, 0, 2, (hipStream_t)stream));
+}
+
+int skv_apply_rotary_pos_emb(const void* x, const void* cos, const void* sin, const int64_t* position_ids,
+                             void* output, int batch_size, int heads, int seq_len, int embed_dim, int stride_xb,
+                             int stride_xh, int stride_xs, int stride_xe, int stride_cos, int stride_sin,
+                             int stride_pid_b, int stride_pid_h, int stride_pid_s, int half_dim,
+                             skv_stream_t stream) {
+    if (!x || !cos || !sin || !position_ids || !output) return SKV_ERR_ARG;
+    return finish(skv_launch_rope_plain(x, cos, sin, stride_sin, position_ids, output, batch_size, heads, seq_len,
+                                        embed_dim, stride_xb, stride_xh, stride_xs, stride_xe, stride_cos,
+                                        stride_pid_b, stride_pid_h, stride_pid_s, half_dim, (hipStream_t)stream));
+}
+
+// ---------------------------------------------------------------- part 2: fused decode path
+size_t skv_select_workspace_bytes(int blocks, int groups, int n_landmarks) {
+    return carve_select_ws(nullptr, blocks, groups, n_landmarks).total;
+}
+
+int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                      int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
+                      int blocks, int groups, int n_landmarks, int select_sets, float alpha, skv_stream_t stream) {
+    if (!q || !landmarks || !cached_pos_ids || !offsets || !cnts || !workspace) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st);
+    if (rc != SKV_OK) return rc;
+    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, blocks, groups, n_landmarks, st);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_topk_reorder(w.score, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
+                                          selected_out, blocks, n_landmarks, select_sets, st));
+}
+
+int skv_move_chunks(const void* host_values, void* cache_buffer, const int32_t* offsets, const int32_t* cnts,
+                    uint32_t* signals, long long host_block_stride, long long cache_block_stride,
+                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream) {
+    if (!cache_buffer || !offsets || !cnts || !signals) return SKV_ERR_ARG;
+    return finish(skv_launch_move_rows(host_values, cache_buffer, offsets, cnts, signals, host_block_stride,
+                                       cache_block_stride, cache_sparse_offset, blocks, select_sets,
+                                       (hipStream_t)stream));
+}
+
+int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,
+                     const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
+                     int rank, int select_sets, int chunk_size, long long cos_sin_stride,
+                     long long cache_stride_b, long long cache_stride_h, long long cache_stride_s,
+                     int sparse_start, int rope_mode, skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !chunk_ids || !cnts || !k_cache) return SKV_ERR_ARG;
+    if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
+    return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len,
+                                     head_dim, rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b,
+                                     cache_stride_h, cache_stride_s, sparse_start, rope_mode,
+                                     (hipStream_t)stream));
+}
+
+int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,
+                         const int32_t* kv_len_dev, int kv_len, long long kv_head_stride, int batch_size,
+                         int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream) {
+    if (!q || !k || !v || !out || !workspace) return SKV_ERR_ARG;
+    return finish(skv_launch_sparse_attention(q, k, v, out, workspace, kv_len_dev, kv_len, kv_head_stride,
+                                              batch_size, q_heads, kv_heads, head_dim, splits, scale,
+                                              (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// Sparse decode attention over the assembled buffers [local | outlier | selected | generated]
+// (SURVEY.md section 8 row a11).  Replaces the reference's call into flash-attn
+// (/root/reference/models/base.py:341, flash_attn_with_kvcache(q[bs,1,Hq,128], k/v[bs,len,Hkv,128])).
+//
+// q_len == 1, GQA: the G = Hq/Hkv query heads of one KV head share every K/V row, so a
+// workgroup streams each K/V row once and serves all G heads.  The KV range of a (batch, kv head)
+// is split over `splits` workgroups (flash-decoding): 8 KV heads alone would leave 248 CUs idle.
+//   pass 1  grid (splits, bs*Hkv): a 16-lane group owns one key at a time - the 16 lanes hold the
+//           256-B K row (16 B each), finish q.k with a 4-step butterfly, keep an online softmax
+//           (m, l) per query head and accumulate p*V for their 8 output dims; the 16 groups of the
+//           workgroup are merged through LDS; (m, l, acc[128]) per (split, head) go to a workspace.
+//   pass 2  grid (bs*Hq): merges the splits, writes bf16.
+// HBM-bound: 2 * kv_len * 256 B per (batch, kv head); K/V rows are read exactly once.
+// kv_len may come from device memory (kv_len_dev) so the launch sequence is graph-capturable.
+#include "../../include/shadowkv_hip.h"
+#include "skv_common.h"
+
+#define AT_D 128
+#define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
+
+template <int G>
+__global__ __launch_bounds__(256) void skv_attn_partial_kernel(
+    const bf16_t* __restrict__ q,   // [bs][Hq][128]
+    const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
+    const bf16_t* __restrict__ v,
+    float* __restrict__ ws,         // [bs*Hkv][splits][G][130]  (m, l, acc[128])
+    const int* __restrict__ kv_len_dev, int kv_len_host, long long kv_stride_h /*elements*/, int Hkv, int splits,
+    float scale) {
+    const int bh = blockIdx.y, split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
+    const int kv_len = kv_len_dev ? *kv_len_dev : kv_len_host;
+    const int per = (kv_len + splits - 1) / splits;
+    const int k0 = split * per, k1 = min(k0 + per, kv_len);
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        u32x4 w = *reinterpret_cast<const u32x4*>(q + ((size_t)bh * G + g) * AT_D + 8 * sub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[g][2 * j] = bf_lo(w[j]) * scale;
+            qf[g][2 * j + 1] = bf_hi(w[j]) * scale;
+        }
+    }
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+    const bf16_t* kb = k + (size_t)bh * kv_stride_h + 8 * sub;
+    const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
+    for (int key = k0 + grp; key < k1; key += AT_GROUPS) {
+        u32x4 kr = *reinterpret_cast<const u32x4*>(kb + (size_t)key * AT_D);
+        u32x4 vr = *reinterpret_cast<const u32x4*>(vb + (size_t)key * AT_D);
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kf[2 * j] = bf_lo(kr[j]);
+            kf[2 * j + 1] = bf_hi(kr[j]);
+            vf[2 * j] = bf_lo(vr[j]);
+            vf[2 * j + 1] = bf_hi(vr[j]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = __builtin_fmaf(qf[g][j], kf[j], s);
+            s = row16_tree_sum(s);
+            float mn = fmaxf(m[g], s);
+            float corr = __expf(m[g] - mn);
+            float p = __expf(s - mn);
+            l[g] = l[g] * corr + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] = __builtin_fmaf(p, vf[j], acc[g][j] * corr);
+            m[g] = mn;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[g][j];
+        if (sub == 0) {
+            s_part[grp][g][AT_D] = m[g];
+            s_part[grp][g][AT_D + 1] = l[g];
+        }
+    }
+    __syncthreads();
+    // merge the 16 groups: thread handles (g, d) pairs; G*128 outputs + G stats
+    for (int o = tid; o < G * AT_D; o += 256) {
+        const int g = o / AT_D, d = o % AT_D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
+        float a = 0.f, L = 0.f;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) {
+            float mr = s_part[r][g][AT_D];
+            float w = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+            a = __builtin_fmaf(s_part[r][g][d], w, a);
+            L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
+        }
+        float* dst = ws + (((size_t)bh * splits + split) * G + g) * (AT_D + 2);
+        dst[d] = a;
+        if (d == 0) {
+            dst[AT_D] = M;
+            dst[AT_D + 1] = L;
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
+                                                               int G, int splits) {
+    // block = one query head (b, hq); thread = output dim
+    const int bq = blockIdx.x, d = threadIdx.x;
+    const int bh = bq / G, g = bq % G;
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, ws[(((size_t)bh * splits + s) * G + g) * (AT_D + 2) + AT_D]);
+    float a = 0.f, L = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float* p = ws + (((size_t)bh * splits + s) * G + g) * (AT_D + 2);
+        float w = (p[AT_D] == -INFINITY) ? 0.f : __expf(p[AT_D] - M);
+        a = __builtin_fmaf(p[d], w, a);
+        L = __builtin_fmaf(p[AT_D + 1], w, L);
+    }
+    out[(size_t)bq * AT_D + d] = f2bf(a / L);
+}
+
+extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return (size_t)bs * Hq * splits * (AT_D + 2) * sizeof(float); }
+
+int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
+                                const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
+                                int Hkv, int head_dim, int splits, float scale, hipStream_t st) {
+    if (head_dim != AT_D || Hkv < 1 || Hq % Hkv != 0 || splits < 1) return SKV_ERR_UNSUPPORTED;
+    const int G = Hq / Hkv;
+    dim3 grid(splits, bs * Hkv), block(256);
+    const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float);
+#define SKV_AT(GG)                                                                                              \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set && smem > 64 * 1024) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)skv_attn_partial_kernel<GG>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((skv_attn_partial_kernel<GG>), grid, block, smem, st, (const bf16_t*)q,              \
+                           (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_stride_h, \
+                           Hkv, splits, scale);                                                                 \
+    } while (0)
+    switch (G) {
+        case 1: SKV_AT(1); break;
+        case 2: SKV_AT(2); break;
+        case 4: SKV_AT(4); break;
+        case 8: SKV_AT(8); break;
+        default: return SKV_ERR_UNSUPPORTED;
+    }
+#undef SKV_AT
+    hipLaunchKernelGGL(skv_attn_combine_kernel, dim3(bs * Hq), dim3(128), 0, st, (const float*)ws, (bf16_t*)out, G,
+                       splits);
+    return SKV_OK;
+}

@@ -1,0 +1,201 @@
+// K reconstruction for the chunks that missed the cache:
+//     k[b,h,i,:] = RoPE( bf16( U[b, pos(i), 0:R] . SV[b,h,:,0:R]^T ), pos(i) ),   pos(i) = id[i/C]*C + i%C
+// written straight into the sparse region of the key cache, for rows of chunks >= cnt[b,h].
+//
+// Replaces /root/reference/kernels/batch_gather_gemm.cu:193-287 (CUTLASS gather-GEMM, bf16 result
+// round-tripped through HBM) + /root/reference/kernels/rope_new.cu:321-411 / :429-534 (RoPE-and-push).
+// The reference meant to fuse RoPE into the GEMM epilogue and left it disabled
+// (batch_gather_gemm_epilogue.h:589-607); here it IS fused, with the same rounding points: the f32
+// accumulator is rounded to bf16 first, then rotated in bf16 arithmetic (three roundings per output).
+//
+// MI355X mapping: one workgroup = 64 rows (8 chunks) x 128 columns, 4 waves x (16 rows x 128 cols).
+//   A (U rows)  : gathered straight from HBM in MFMA fragment shape - lane l reads the 16 B
+//                 U[pos(row l&15)][32*ks + 8*(l>>4) ...], all 5 k-steps issued up front;
+//                 the 8 rows of a chunk are 2,560 contiguous bytes.
+//   B (SV[h])   : 40 KB, staged once per workgroup into LDS with rows padded 320 -> 336 B so the
+//                 16-row x 16-B ds_read_b128 fragments are bank-conflict free.
+//   v_mfma_f32_16x16x32_bf16, 8 column blocks x 5 k-steps per wave.
+//   epilogue    : accumulators -> bf16 -> LDS tile; second pass reads whole rows, applies RoPE with
+//                 16-B cos/sin loads and stores 16 B per lane (256-B rows, fully coalesced).
+// Whole tiles below cnt*C exit early; rows below cnt*C inside a partial tile are computed but not
+// stored (they hold resident chunks).  The legacy entry point (pre-RoPE output buffer) shares the kernel.
+#include "skv_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RB_ROWS 64
+#define RB_D 128
+#define RB_SV_PITCH 336  // bytes per SV row in LDS (320 + 16 pad)
+#define RB_OUT_PITCH 272 // bytes per output row in LDS (256 + 16 pad)
+
+template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/>
+__global__ __launch_bounds__(256) void skv_rebuild_kernel(
+    const bf16_t* __restrict__ U,        // [bs][seq_len][R]
+    const bf16_t* __restrict__ SV,       // [bs][heads][128][R]
+    const bf16_t* __restrict__ cos_sin,  // [max_pos][cs_stride]
+    const void* __restrict__ ids,        // [bs][heads][S] chunk id per slot (int64 or int32)
+    const int32_t* __restrict__ cnts,    // [bs*heads] (nullable -> 0)
+    bf16_t* __restrict__ out,            // MODE 0: [bs][heads][S*C][128]; else key cache
+    int heads, int seq_len, int R, int S, int C, int ids64, long long cs_stride,
+    long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sSV = smem;                         // 128 x 336 B
+    unsigned char* sOut = smem + RB_D * RB_SV_PITCH;   // 64 x 272 B
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int i0 = blockIdx.x * RB_ROWS;
+    const int total_rows = S * C;
+    const int cnt = cnts ? cnts[bh] : 0;
+    if (i0 + RB_ROWS <= cnt * C) return;  // every row of this tile is a resident (hit) row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ksteps = R / 32;
+
+    // ---- A fragments: issue the gathers first
+    const int arow = i0 + wave * 16 + (lane & 15);
+    long long pos = 0;
+    if (arow < total_rows) {
+        long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + arow / C]
+                             : (long long)((const int32_t*)ids)[(size_t)bh * S + arow / C];
+        pos = id * C + arow % C;
+        if (pos < 0 || pos >= seq_len) pos = 0;  // invalid ids are a caller error; never fault
+    }
+    const bf16_t* urow = U + ((size_t)b * seq_len + pos) * R + 8 * (lane >> 4);
+    u32x4 afrag[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        if (ks < ksteps) afrag[ks] = *reinterpret_cast<const u32x4*>(urow + 32 * ks);
+
+    // ---- stage SV[b][h] (128 rows x R) into LDS
+    {
+        const int units_per_row = R / 8;  // 16-B units
+        const int total_units = RB_D * units_per_row;
+        const u32x4* src = reinterpret_cast<const u32x4*>(SV + (size_t)bh * RB_D * R);
+        for (int u = tid; u < total_units; u += 256) {
+            int row = u / units_per_row, c16 = u % units_per_row;
+            *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = src[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA: acc[nb] covers rows wave*16.., columns nb*16..
+    f32x4 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks < ksteps) {
+            bf16x8 a = __builtin_bit_cast(bf16x8, afrag[ks]);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                u32x4 braw = *reinterpret_cast<const u32x4*>(sSV + (nb * 16 + (lane & 15)) * RB_SV_PITCH + ks * 64 +
+                                                              (lane >> 4) * 16);
+                bf16x8 bb = __builtin_bit_cast(bf16x8, braw);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- accumulators -> bf16 tile in LDS (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = wave * 16 + (lane >> 4) * 4 + r, col = nb * 16 + (lane & 15);
+            *reinterpret_cast<bf16_t*>(sOut + row * RB_OUT_PITCH + col * 2) = f2bf(acc[nb][r]);
+        }
+    __syncthreads();
+
+    // ---- row-wise epilogue
+    if (MODE == 0) {
+        // 64 rows x 16 units of 16 B
+        for (int u = tid; u < RB_ROWS * 16; u += 256) {
+            int row = u >> 4, c16 = u & 15, i = i0 + row;
+            if (i >= total_rows || i < cnt * C) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c16 * 16);
+            *reinterpret_cast<u32x4*>(out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
+                                      (size_t)(out_row0 + i) * out_stride_s + c16 * 8) = v;
+        }
+    } else if (MODE == 1) {
+        // NeoX half split: unit u (0..7) pairs elements [8u, 8u+8) with [64+8u, 64+8u+8)
+        for (int u = tid; u < RB_ROWS * 8; u += 256) {
+            int row = u >> 3, c = u & 7, i = i0 + row;
+            if (i >= total_rows || i < cnt * C) continue;
+            long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + i / C]
+                                 : (long long)((const int32_t*)ids)[(size_t)bh * S + i / C];
+            long long p = id * C + i % C;
+            const bf16_t* cs = cos_sin + p * cs_stride;
+            u32x4 x1 = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
+            u32x4 x2 = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + 128 + c * 16);
+            u32x4 cc = *reinterpret_cast<const u32x4*>(cs + 8 * c);
+            u32x4 ss = *reinterpret_cast<const u32x4*>(cs + 64 + 8 * c);
+            u32x4 o1, o2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a0 = bf_lo(x1[j]), a1 = bf_hi(x1[j]), b0 = bf_lo(x2[j]), b1 = bf_hi(x2[j]);
+                float c0 = bf_lo(cc[j]), c1 = bf_hi(cc[j]), s0 = bf_lo(ss[j]), s1 = bf_hi(ss[j]);
+                float r0 = bfr(a0 * c0) + bfr(-b0 * s0), r1 = bfr(a1 * c1) + bfr(-b1 * s1);
+                float t0 = bfr(b0 * c0) + bfr(a0 * s0), t1 = bfr(b1 * c1) + bfr(a1 * s1);
+                o1[j] = pack_bf2(r0, r1);
+                o2[j] = pack_bf2(t0, t1);
+            }
+            bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
+                           (size_t)(out_row0 + i) * out_stride_s;
+            *reinterpret_cast<u32x4*>(orow + 8 * c) = o1;
+            *reinterpret_cast<u32x4*>(orow + 64 + 8 * c) = o2;
+        }
+    } else {
+        // GLM: dims 0..63 interleaved pairs (2t, 2t+1) with cos = cs[t], sin = cs[32+t]; 64..127 copied
+        for (int u = tid; u < RB_ROWS * 16; u += 256) {
+            int row = u >> 4, c = u & 15, i = i0 + row;
+            if (i >= total_rows || i < cnt * C) continue;
+            u32x4 x = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
+            u32x4 o = x;
+            if (c < 8) {
+                long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + i / C]
+                                     : (long long)((const int32_t*)ids)[(size_t)bh * S + i / C];
+                long long p = id * C + i % C;
+                const bf16_t* cs = cos_sin + p * cs_stride;
+                u32x2 cc = *reinterpret_cast<const u32x2*>(cs + 4 * c);       // cos[4c .. 4c+3]
+                u32x2 ss = *reinterpret_cast<const u32x2*>(cs + 32 + 4 * c);  // sin[4c .. 4c+3]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xe = bf_lo(x[j]), xo = bf_hi(x[j]);
+                    uint32_t cw = cc[j >> 1], sw = ss[j >> 1];
+                    float cv = (j & 1) ? bf_hi(cw) : bf_lo(cw);
+                    float sv = (j & 1) ? bf_hi(sw) : bf_lo(sw);
+                    float oe = bfr(xe * cv) + bfr(-xo * sv);
+                    float oo = bfr(xo * cv) + bfr(xe * sv);
+                    o[j] = pack_bf2(oe, oo);
+                }
+            }
+            bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
+                           (size_t)(out_row0 + i) * out_stride_s;
+            *reinterpret_cast<u32x4*>(orow + 8 * c) = o;
+        }
+    }
+}
+
+// mode: 0 pre-RoPE (legacy batch_gather_gemm), 1 Llama, 2 GLM
+int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
+                       const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
+                       int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
+                       long long out_stride_s, int out_row0, int mode, hipStream_t st) {
+    if (head_dim != RB_D || R % 32 != 0 || R < 32 || R > 256 || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
+    if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
+    if (mode == 1 && cs_stride < 128) return SKV_ERR_ARG;
+    if (mode == 2 && cs_stride < 64) return SKV_ERR_ARG;
+    // LDS pitch is fixed for R <= 160; larger ranks need a wider pitch
+    if (R > 160) return SKV_ERR_UNSUPPORTED;
+    const int tiles = (S * C + RB_ROWS - 1) / RB_ROWS;
+    const size_t smem = RB_D * RB_SV_PITCH + RB_ROWS * RB_OUT_PITCH;
+    dim3 grid(tiles, bs * heads), block(256);
+#define SKV_RB(M)                                                                                                  \
+    hipLaunchKernelGGL((skv_rebuild_kernel<M>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,        \
+                       (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, R, S, C, ids64, cs_stride, \
+                       out_stride_b, out_stride_h, out_stride_s, out_row0)
+    if (mode == 0) SKV_RB(0);
+    else if (mode == 1) SKV_RB(1);
+    else if (mode == 2) SKV_RB(2);
+    else return SKV_ERR_ARG;
+#undef SKV_RB
+    return SKV_OK;
+}

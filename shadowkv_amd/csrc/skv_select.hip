@@ -1,0 +1,459 @@
+// Chunk selection for one decode step:
+//   skv_score_tile_kernel        q . landmarks^T  -> bf16 logits + per-256-column partial (max, sum)
+//   skv_softmax_final_kernel     partials -> (max, 1/sum) per row              [legacy 3-stage API]
+//   skv_softmax_apply_kernel     P = bf16(exp(D-max)*inv)                      [legacy 3-stage API]
+//   skv_normalize_groupmax_kernel  partials -> P -> max over the GQA group -> bf16 score per landmark
+//   skv_topk_reorder_kernel      exact top-k (ties -> lowest slot), slot->chunk id, hit/miss diff
+//                                against the resident chunk set, two sorts, offsets, cnts
+//
+// Replaces /root/reference/kernels/batch_gemm_softmax.{cu,h} (CUTLASS), the torch.max /
+// torch.topk / gather chain at /root/reference/models/kv_cache.py:1023-1042 and
+// /root/reference/kernels/map.cuh:754-796.  Arithmetic contract: skv_common.h ==
+// oracle/shadowkv_oracle.c.
+//
+// Roofline: the scoring kernel streams the landmark table once (B*N*256 bytes, 31.9 MB per
+// layer at the headline config) and is HBM-bound; everything after it touches <= 1.3 MB.
+#include "skv_common.h"
+
+#define SKV_TILE 256  // columns per partial tile == the reference's ThreadblockShape::kN
+
+// ---------------------------------------------------------------------------------------
+// K1: scoring.  One workgroup (4 waves) per 256-landmark tile.  A wave-instruction loads
+// 4 landmark rows (16 lanes x 16 B each, 1 KiB coalesced); lane `sub` of a row holds the
+// 8 contiguous elements k = 8*sub..8*sub+7, multiplies them into G running sums (q lives
+// in registers), and a 4-step butterfly over the 16 lanes finishes the dot product.
+// 16 loads (64 rows per wave) are issued before the first use.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void skv_score_tile_kernel(
+    const bf16_t* __restrict__ q,    // [B][G][128]
+    const bf16_t* __restrict__ lm,   // [B][N][128]
+    bf16_t* __restrict__ D,          // [B][G][N]
+    float* __restrict__ part_max,    // [B][T][G]
+    float* __restrict__ part_sum,    // [B][T][G]
+    int N, int T, float alpha) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, rsel = lane >> 4;
+    __shared__ bf16_t sD[G][SKV_TILE];
+    __shared__ float s_red_m[4][G];
+    __shared__ unsigned long long s_red_s[4][G];
+    __shared__ float s_m[G];
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        u32x4 w = *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + g) * 128 + 8 * sub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[g][2 * j] = bf_lo(w[j]);
+            qf[g][2 * j + 1] = bf_hi(w[j]);
+        }
+    }
+
+    const int row0 = t * SKV_TILE + wave * 64 + rsel;
+    u32x4 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int row = row0 + i * 4;
+        row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
+        x[i] = *reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float xf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xf[2 * j] = bf_lo(x[i][j]);
+            xf[2 * j + 1] = bf_hi(x[i][j]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(qf[g][j], xf[j], acc);
+            acc = row16_tree_sum(acc);
+            bf16_t d = f2bf(alpha * acc);
+            if (sub == (g & 15)) sD[g][wave * 64 + i * 4 + rsel] = d;
+        }
+    }
+    __syncthreads();
+
+    // per-tile statistics; thread `tid` owns column `tid`
+    const int col = t * SKV_TILE + tid;
+    const bool valid = col < N;
+    float dv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        dv[g] = bf2f(sD[g][tid]);
+        float m = wave_max(valid ? dv[g] : -INFINITY);
+        if (lane == 0) s_red_m[wave][g] = m;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float m = fmaxf(fmaxf(s_red_m[0][tid], s_red_m[1][tid]), fmaxf(s_red_m[2][tid], s_red_m[3][tid]));
+        s_m[tid] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        unsigned long long e = valid ? exp_to_fixed(spec_exp(dv[g] - s_m[g])) : 0ull;
+        e = wave_sum_u64(e);
+        if (lane == 0) s_red_s[wave][g] = e;
+        if (valid) D[((size_t)b * G + g) * N + col] = sD[g][tid];
+    }
+    __syncthreads();
+    if (tid < G) {
+        unsigned long long S = s_red_s[0][tid] + s_red_s[1][tid] + s_red_s[2][tid] + s_red_s[3][tid];
+        part_max[((size_t)b * T + t) * G + tid] = s_m[tid];
+        part_sum[((size_t)b * T + t) * G + tid] = fixed_to_float(S);
+    }
+}
+
+// final (max, 1/sum) of one softmax row from its T tile partials; executed by one full wave.
+// pm / ps point at element [tile 0] of the row, consecutive tiles are `stride` floats apart.
+__device__ __forceinline__ void softmax_finalize_wave(const float* pm, const float* ps, int T, int stride,
+                                                      int lane, float& m_out, float& inv_out) {
+    float m = -INFINITY;
+    for (int tt = lane; tt < T; tt += 64) m = fmaxf(m, pm[(size_t)tt * stride]);
+    m = wave_max(m);
+    float acc = 0.0f;
+    for (int tt = lane; tt < T; tt += 64) acc = acc + ps[(size_t)tt * stride] * spec_exp(pm[(size_t)tt * stride] - m);
+    float s = wave_tree_sum(acc);
+    m_out = m;
+    inv_out = 1.0f / s;
+}
+
+// legacy stage 2: one wave per (batch, row); writes the finals into the tile-0 slots
+// (what the apply stage reads, /root/reference/kernels/batch_gemm_softmax.h:274-275).
+__global__ __launch_bounds__(64) void skv_softmax_final_kernel(float* part_max, float* part_sum, int m, int T) {
+    const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    float* pm = part_max + (size_t)b * T * m + r;
+    float* ps = part_sum + (size_t)b * T * m + r;
+    float mx, inv;
+    softmax_finalize_wave(pm, ps, T, m, lane, mx, inv);
+    // all lanes have finished reading the partials (the reductions above are wave-wide)
+    if (lane == 0) {
+        pm[0] = mx;
+        ps[0] = inv;
+    }
+}
+
+// legacy stage 3
+__global__ __launch_bounds__(256) void skv_softmax_apply_kernel(const bf16_t* __restrict__ D,
+                                                                const float* __restrict__ part_max,
+                                                                const float* __restrict__ part_sum,
+                                                                bf16_t* __restrict__ P, int m, int N, int T) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    const float mx = part_max[(size_t)b * T * m + r];
+    const float inv = part_sum[(size_t)b * T * m + r];
+    const size_t o = ((size_t)b * m + r) * N + col;
+    P[o] = f2bf(spec_exp(bf2f(D[o]) - mx) * inv);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2a: finals recomputed per workgroup from the partials (no cross-workgroup hand-off),
+// P = bf16(exp(D - m) * inv), score = max over the G query heads of the group.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
+    const bf16_t* __restrict__ D, const float* __restrict__ part_max, const float* __restrict__ part_sum,
+    bf16_t* __restrict__ P /* nullable, [B][G][N] */, bf16_t* __restrict__ score /* [B][N] */, int N, int T) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_m[G], s_inv[G];
+    for (int g = wave; g < G; g += 4) {
+        float mx, inv;
+        softmax_finalize_wave(part_max + (size_t)b * T * G + g, part_sum + (size_t)b * T * G + g, T, G, lane, mx, inv);
+        if (lane == 0) {
+            s_m[g] = mx;
+            s_inv[g] = inv;
+        }
+    }
+    __syncthreads();
+    const int col = t * SKV_TILE + tid;
+    if (col >= N) return;
+    bf16_t best = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const size_t o = ((size_t)b * G + g) * N + col;
+        bf16_t p = f2bf(spec_exp(bf2f(D[o]) - s_m[g]) * s_inv[g]);
+        if (P) P[o] = p;
+        best = p > best ? p : best;  // p >= 0: unsigned order == float order
+    }
+    score[(size_t)b * N + col] = best;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2b: top-k + diff.  One 1024-thread workgroup per (batch, kv head).
+// ---------------------------------------------------------------------------------------
+#define SKV_SEL_THREADS 1024
+
+// inclusive scan of one int per thread over the 1024-thread workgroup
+__device__ __forceinline__ int block_scan_incl(int v, int* s_wave /*[16]*/, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    if (tid < 16) {
+        int w = s_wave[tid];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            int n = __shfl_up(w, o, 64);
+            if (tid >= o) w += n;
+        }
+        s_wave[tid] = w;
+    }
+    __syncthreads();
+    int base = wave > 0 ? s_wave[wave - 1] : 0;
+    __syncthreads();  // s_wave may be reused by the next call
+    return v + base;
+}
+
+// Given a 256-bin histogram in LDS (ascending key order), find the bin holding the k-th
+// LARGEST element.  Returns bin in *bin_out and the number of elements in higher bins in
+// *above_out (both broadcast through LDS).  Threads 0..255 participate; all must call.
+__device__ __forceinline__ void select_bin_desc(const int* hist, int k, int* s_wave, int* s_out, int tid) {
+    int c = tid < 256 ? hist[255 - tid] : 0;  // descending
+    int incl = block_scan_incl(c, s_wave, tid);
+    if (tid < 256 && incl >= k && incl - c < k) {
+        s_out[0] = 255 - tid;
+        s_out[1] = incl - c;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
+    const bf16_t* __restrict__ score,      // [B][N] (nullable: then cur_in is used)
+    const int64_t* __restrict__ lm_idx,    // [B][N] slot -> chunk id (nullable: identity)
+    const int64_t* __restrict__ cur_in,    // [B][S] ids selected by the caller (legacy path)
+    int64_t* __restrict__ cached,          // [B][S] in: resident ids per slot; out: reordered ids
+    int32_t* __restrict__ offsets,         // [B][S] out
+    int32_t* __restrict__ cnts,            // [B] out
+    int64_t* __restrict__ sel_out,         // [B][S] nullable: ids selected this step, ascending slot
+    int N, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* s_cur = smem;            // [SP]
+    int* s_hkeys = s_cur + SP;    // [H]
+    int* s_hvals = s_hkeys + H;   // [H]
+    int* s_byslot = s_hvals + H;  // [SP]  hit key by old slot, -1 if none
+    int* s_sortk = s_byslot + SP; // [SP]  misses (sorted in place)
+    int* s_hist = s_sortk + SP;   // [256]
+    int* s_wave = s_hist + 256;   // [16]
+    int* s_out = s_wave + 16;     // [4]
+    const int b = blockIdx.x, tid = threadIdx.x;
+
+    if (score != nullptr) {
+        const bf16_t* sc = score + (size_t)b * N;
+        // ---- pass 1: histogram of the high byte
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < N; j += SKV_SEL_THREADS) atomicAdd(&s_hist[sc[j] >> 8], 1);
+        __syncthreads();
+        select_bin_desc(s_hist, S, s_wave, s_out, tid);
+        const int hi = s_out[0], above_hi = s_out[1];
+        __syncthreads();
+        // ---- pass 2: histogram of the low byte inside that bin
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < N; j += SKV_SEL_THREADS) {
+            bf16_t v = sc[j];
+            if ((v >> 8) == hi) atomicAdd(&s_hist[v & 0xff], 1);
+        }
+        __syncthreads();
+        select_bin_desc(s_hist, S - above_hi, s_wave, s_out, tid);
+        const int thr = (hi << 8) | s_out[0];
+        const int n_gt = above_hi + s_out[1];
+        const int need_eq = S - n_gt;
+        __syncthreads();
+        // ---- pass 3: ordered compaction; thread owns a contiguous index segment
+        const int seg = (N + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
+        const int j0 = tid * seg, j1 = min(j0 + seg, N);
+        int c_gt = 0, c_eq = 0;
+        for (int j = j0; j < j1; ++j) {
+            int v = sc[j];
+            c_gt += v > thr;
+            c_eq += v == thr;
+        }
+        int gt_before = block_scan_incl(c_gt, s_wave, tid) - c_gt;
+        int eq_before = block_scan_incl(c_eq, s_wave, tid) - c_eq;
+        for (int j = j0; j < j1; ++j) {
+            int v = sc[j];
+            int pos = -1;
+            if (v > thr) {
+                pos = gt_before + min(eq_before, need_eq);
+                ++gt_before;
+            } else if (v == thr) {
+                if (eq_before < need_eq) pos = gt_before + eq_before;
+                ++eq_before;
+            }
+            if (pos >= 0) {
+                long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
+                s_cur[pos] = (int)id;
+                if (sel_out) sel_out[(size_t)b * S + pos] = id;
+            }
+        }
+    } else {
+        if (tid < S) s_cur[tid] = (int)cur_in[(size_t)b * S + tid];
+    }
+
+    // ---- hash set of resident ids: key -> lowest slot
+    for (int i = tid; i < H; i += SKV_SEL_THREADS) {
+        s_hkeys[i] = -1;
+        s_hvals[i] = 0x7fffffff;
+    }
+    for (int i = tid; i < SP; i += SKV_SEL_THREADS) s_byslot[i] = -1;
+    __syncthreads();
+    if (tid < S) {
+        int key = (int)cached[(size_t)b * S + tid];
+        if (key >= 0) {
+            unsigned pos = (unsigned)key & (unsigned)(H - 1);
+            for (int probe = 0; probe < H; ++probe) {
+                int prev = atomicCAS(&s_hkeys[pos], -1, key);
+                if (prev == -1 || prev == key) {
+                    atomicMin(&s_hvals[pos], tid);
+                    break;
+                }
+                pos = (pos + 1) & (unsigned)(H - 1);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- classify the new ids
+    int my_key = -1, my_slot = -1;
+    if (tid < S) {
+        my_key = s_cur[tid];
+        if (my_key >= 0) {
+            unsigned pos = (unsigned)my_key & (unsigned)(H - 1);
+            for (int probe = 0; probe < H; ++probe) {
+                int k2 = s_hkeys[pos];
+                if (k2 == my_key) {
+                    my_slot = s_hvals[pos];
+                    break;
+                }
+                if (k2 == -1) break;
+                pos = (pos + 1) & (unsigned)(H - 1);
+            }
+        }
+        if (my_slot >= 0) s_byslot[my_slot] = my_key;
+    }
+    __syncthreads();
+    // hits ordered by old slot: compaction of s_byslot
+    const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
+    const int hit_incl = block_scan_incl(is_hit_slot, s_wave, tid);
+    if (tid == SKV_SEL_THREADS - 1) s_out[2] = hit_incl;
+    // misses in selection order, then sorted by id
+    const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
+    const int miss_incl = block_scan_incl(is_miss, s_wave, tid);
+    __syncthreads();
+    const int cnt = s_out[2];
+    for (int i = tid; i < SP; i += SKV_SEL_THREADS) s_sortk[i] = 0x7fffffff;
+    __syncthreads();
+    if (is_miss) s_sortk[miss_incl - 1] = my_key;
+    __syncthreads();
+    // bitonic sort of s_sortk[0..SP) ascending (signed)
+    for (int size = 2; size <= SP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < SP; i += SKV_SEL_THREADS) {
+                int ixj = i ^ stride;
+                if (ixj > i) {
+                    bool asc = (i & size) == 0;
+                    int a = s_sortk[i], c = s_sortk[ixj];
+                    if ((a > c) == asc) {
+                        s_sortk[i] = c;
+                        s_sortk[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- write out
+    if (is_hit_slot) {
+        int o = hit_incl - 1;
+        cached[(size_t)b * S + o] = (long long)s_byslot[tid];
+        offsets[(size_t)b * S + o] = tid;
+    }
+    if (tid < S - cnt) {
+        int key = s_sortk[tid];
+        cached[(size_t)b * S + cnt + tid] = (long long)key;
+        offsets[(size_t)b * S + cnt + tid] = key;
+    }
+    if (tid == 0) cnts[b] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+static inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <int G>
+static int launch_score_g(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int N, int T,
+                          float alpha, hipStream_t st) {
+    hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha);
+    return SKV_OK;
+}
+
+int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
+                     float alpha, hipStream_t st) {
+    const int T = (N + SKV_TILE - 1) / SKV_TILE;
+    switch (G) {
+        case 1: return launch_score_g<1>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        case 2: return launch_score_g<2>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        case 4: return launch_score_g<4>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        case 8: return launch_score_g<8>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        case 16: return launch_score_g<16>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        default: return SKV_ERR_UNSUPPORTED;
+    }
+}
+
+int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void* P, int B, int m, int N,
+                                   hipStream_t st) {
+    const int T = (N + SKV_TILE - 1) / SKV_TILE;
+    hipLaunchKernelGGL(skv_softmax_final_kernel, dim3(m, B), dim3(64), 0, st, pmax, psum, m, T);
+    hipLaunchKernelGGL(skv_softmax_apply_kernel, dim3((N + 255) / 256, m, B), dim3(256), 0, st, (const bf16_t*)D,
+                       (const float*)pmax, (const float*)psum, (bf16_t*)P, m, N, T);
+    return SKV_OK;
+}
+
+int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score, int B,
+                                  int G, int N, hipStream_t st) {
+    const int T = (N + SKV_TILE - 1) / SKV_TILE;
+#define SKV_NG(GG)                                                                                              \
+    hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(T, B), dim3(256), 0, st, (const bf16_t*)D, pmax, \
+                       psum, (bf16_t*)P, (bf16_t*)score, N, T)
+    switch (G) {
+        case 1: SKV_NG(1); break;
+        case 2: SKV_NG(2); break;
+        case 4: SKV_NG(4); break;
+        case 8: SKV_NG(8); break;
+        case 16: SKV_NG(16); break;
+        default: return SKV_ERR_UNSUPPORTED;
+    }
+#undef SKV_NG
+    return SKV_OK;
+}
+
+int skv_launch_topk_reorder(const void* score, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
+                            int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
+                            hipStream_t st) {
+    if (S < 1 || S > SKV_SEL_THREADS) return SKV_ERR_UNSUPPORTED;
+    if (score != nullptr && N < S) return SKV_ERR_ARG;
+    const int SP = next_pow2(S);
+    const int H = 4 * SP;
+    const size_t smem = (size_t)(SP * 3 + H * 2 + 256 + 16 + 4) * sizeof(int);
+    hipLaunchKernelGGL(skv_topk_reorder_kernel, dim3(B), dim3(SKV_SEL_THREADS), smem, st, (const bf16_t*)score,
+                       lm_idx, cur_in, cached, offsets, cnts, sel_out, N, S, H, SP);
+    return SKV_OK;
+}

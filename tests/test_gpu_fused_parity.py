@@ -1,0 +1,154 @@
+"""GPU parity for the fused decode-path launchers (C ABI part 2) against the CPU oracle."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+import oracle
+from util import ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from shadowkv_amd import _lib
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _oracle_select(q, lm, lm_idx, cached, blocks, G, N, S):
+    T = (N + 255) // 256
+    D = torch.zeros(blocks, G, N, dtype=torch.bfloat16); P = torch.zeros_like(D)
+    nm = torch.zeros(blocks, T, G); sm = torch.zeros(blocks, T, G)
+    oracle.batch_gemm_softmax(q, lm, D, nm, sm, P, blocks, G, N, 128, ALPHA)
+    sel = oracle.group_max_topk(P, lm_idx, blocks, G, N, S)
+    c = cached.clone(); off = torch.zeros(blocks, S, dtype=torch.int32); cnt = torch.zeros(blocks, dtype=torch.int32)
+    oracle.reorder_keys_and_compute_offsets(c, sel, off, cnt, 1, blocks, S)
+    return P, sel, c, off, cnt
+
+
+def _device_select(q, lm, lm_idx, cached, blocks, G, N, S):
+    L = _lib()
+    ws = torch.empty(L.lib().skv_select_workspace_bytes(blocks, G, N), dtype=torch.uint8, device=DEV)
+    P = torch.zeros(blocks, G, N, dtype=torch.bfloat16, device=DEV)
+    sel = torch.zeros(blocks, S, dtype=torch.int64, device=DEV)
+    c = cached.to(DEV); off = torch.zeros(blocks, S, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(blocks, dtype=torch.int32, device=DEV)
+    qd, lmd, lid = q.to(DEV), lm.to(DEV), (lm_idx.to(DEV) if lm_idx is not None else None)
+    rc = L.lib().skv_select_chunks(qd.data_ptr(), lmd.data_ptr(), L.ptr(lid), c.data_ptr(), off.data_ptr(),
+                                   cnt.data_ptr(), ws.data_ptr(), P.data_ptr(), sel.data_ptr(), blocks, G, N, S,
+                                   ALPHA, _stream())
+    L.check(rc, "skv_select_chunks")
+    torch.cuda.synchronize()
+    return P.cpu(), sel.cpu(), c.cpu(), off.cpu(), cnt.cpu()
+
+
+@pytest.mark.parametrize("blocks,G,N,S", [(8, 4, 15560, 256), (8, 4, 504, 32), (4, 8, 25544, 256), (2, 1, 1000, 128),
+                                           (3, 4, 300, 300)])
+def test_select_chunks(blocks, G, N, S):
+    g = torch.Generator().manual_seed(N + S)
+    q = (torch.randn(blocks, G, 128, generator=g) * 3).bfloat16()
+    lm = torch.randn(blocks, N, 128, generator=g).bfloat16()
+    # landmark slot -> chunk id: increasing with gaps (outlier chunks removed), as prefill builds it
+    lm_idx = torch.stack([torch.sort(torch.randperm(N + 48, generator=g)[:N]).values for _ in range(blocks)]).to(torch.int64)
+    cached = torch.stack([lm_idx[b][torch.randperm(N, generator=g)[:S]] for b in range(blocks)])
+    r0 = _oracle_select(q, lm, lm_idx, cached, blocks, G, N, S)
+    r1 = _device_select(q, lm, lm_idx, cached, blocks, G, N, S)
+    assert_bits_equal(r0[0], r1[0], "softmax P")
+    assert torch.equal(r0[1], r1[1]), "selected chunk ids (top-k) differ"
+    assert torch.equal(r0[4], r1[4]), "cnts differ"
+    assert torch.equal(r0[2], r1[2]), "reordered position ids differ"
+    assert torch.equal(r0[3], r1[3]), "offsets differ"
+
+
+def test_select_chunks_ties():
+    """Massive ties at the threshold: duplicated landmarks give identical bf16 scores; the contract
+    (lowest landmark slot wins) must hold bit-exactly."""
+    blocks, G, N, S = 4, 4, 4096, 256
+    g = torch.Generator().manual_seed(77)
+    base = torch.randn(blocks, 37, 128, generator=g).bfloat16()
+    lm = base[:, torch.randint(0, 37, (N,), generator=g)]  # only 37 distinct rows -> huge tie groups
+    q = (torch.randn(blocks, G, 128, generator=g) * 0.5).bfloat16()
+    cached = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(blocks)]).to(torch.int64)
+    r0 = _oracle_select(q, lm.contiguous(), None, cached, blocks, G, N, S)
+    r1 = _device_select(q, lm.contiguous(), None, cached, blocks, G, N, S)
+    assert torch.equal(r0[1], r1[1])
+    assert torch.equal(r0[2], r1[2]) and torch.equal(r0[3], r1[3]) and torch.equal(r0[4], r1[4])
+
+
+@pytest.mark.parametrize("glm", [False, True])
+def test_rebuild_keys(glm):
+    g = torch.Generator().manual_seed(21 + glm)
+    bs, heads, L, R, S, C = 1, 8, 8192, 160, 256, 8
+    U = (torch.randn(bs, L, R, generator=g) / math.sqrt(R)).bfloat16()
+    SV = torch.randn(bs, heads, 128, R, generator=g).bfloat16()
+    ids = torch.stack([torch.randperm(L // C, generator=g)[:S] for _ in range(bs * heads)]).view(bs, heads, S).to(torch.int64)
+    cnts = torch.randint(0, S + 1, (bs * heads,), generator=g, dtype=torch.int32)
+    cnts[0] = 0; cnts[1] = S; cnts[2] = 3
+    width = 64 if glm else 128
+    cs = torch.randn(L + 64, width, generator=g).clamp(-1, 1).bfloat16()
+    start, rows = 448, 448 + S * C + 96
+    cache = torch.randn(bs, heads, rows, 128, generator=g).bfloat16()
+    # oracle: gather-GEMM (bf16 round trip) then RoPE-push
+    tmp = torch.zeros(bs, heads, S * C, 128, dtype=torch.bfloat16)
+    ids32 = ids.to(torch.int32)
+    oracle.batch_gather_gemm(U, SV, None, None, ids32, tmp, bs, heads, L, 128, R, S * C, L, C, torch.zeros_like(cnts))
+    c0 = cache.clone()
+    ints = (bs, heads, S * C, 128, tmp.stride(0), tmp.stride(1), tmp.stride(2), 1, cs.stride(0), ids32.stride(0),
+            ids32.stride(1), ids32.stride(2), c0.stride(0), c0.stride(1), c0.stride(2), start, start + S * C, 64, C)
+    (oracle.apply_rotary_pos_emb_push_cache_opt_glm if glm else oracle.apply_rotary_pos_emb_push_cache_opt)(
+        tmp, cs, ids32, c0, cnts, *ints)
+    L_ = _lib()
+    c1 = cache.to(DEV)
+    Ud, SVd, csd, idd, cnd = U.to(DEV), SV.to(DEV), cs.to(DEV), ids.to(DEV), cnts.to(DEV)
+    rc = L_.lib().skv_rebuild_keys(Ud.data_ptr(), SVd.data_ptr(), csd.data_ptr(), idd.data_ptr(), cnd.data_ptr(),
+                                   c1.data_ptr(), bs, heads, L, 128, R, S, C, cs.stride(0), c1.stride(0),
+                                   c1.stride(1), c1.stride(2), start, 2 if glm else 1, _stream())
+    L_.check(rc, "skv_rebuild_keys")
+    torch.cuda.synchronize()
+    c1 = c1.cpu()
+    # everything outside the rebuilt rows must be untouched, bit for bit
+    for b in range(bs):
+        for h in range(heads):
+            r0 = start + int(cnts[b * heads + h]) * C
+            assert_bits_equal(c0[b, h, :r0], c1[b, h, :r0], "rows below the rebuilt range")
+            assert_bits_equal(c0[b, h, start + S * C:], c1[b, h, start + S * C:], "rows above the sparse region")
+    d = ulp_diff_bf16(c0, c1)
+    # MFMA accumulation order vs the oracle's sequential chain: a flipped bf16 rounding of the
+    # pre-RoPE value moves the rotated value by a few ulps at most (|cos|,|sin| <= 1 and a sum)
+    frac = float((d > 0).sum()) / d.numel()
+    assert frac < 0.03, f"{frac:.4f} of key values differ"
+    rel = (c0.float() - c1.float()).abs() / (c0.float().abs() + 1e-2)
+    assert float(rel.max()) < 2e-2, f"max relative difference {float(rel.max())}"
+
+
+@pytest.mark.parametrize("bs,Hq,Hkv,kv_len,splits", [(1, 32, 8, 2497, 32), (2, 32, 8, 300, 8), (1, 32, 4, 2560, 32),
+                                                     (1, 8, 8, 77, 16), (1, 32, 8, 5, 32)])
+def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
+    g = torch.Generator().manual_seed(kv_len)
+    rows = kv_len + 50
+    q = torch.randn(bs, Hq, 128, generator=g).bfloat16()
+    k = torch.randn(bs, Hkv, rows, 128, generator=g).bfloat16()
+    v = torch.randn(bs, Hkv, rows, 128, generator=g).bfloat16()
+    scale = 1.0 / math.sqrt(128)
+    o0, o0f = oracle.sparse_attention(q, k, v, kv_len, scale)
+    L = _lib()
+    ws = torch.empty(L.lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=DEV)
+    out = torch.zeros(bs, Hq, 128, dtype=torch.bfloat16, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    kv_dev = torch.tensor([kv_len], dtype=torch.int32, device=DEV)
+    for kvp, host_len in ((0, kv_len), (kv_dev.data_ptr(), 0)):
+        out.zero_()
+        rc = L.lib().skv_sparse_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                          kvp, host_len, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream())
+        L.check(rc, "skv_sparse_attention")
+        torch.cuda.synchronize()
+        o1 = out.cpu().float()
+        # tolerance: fp16-level 1e-3 relative (north_star) + half a bf16 ulp of the output rounding
+        tol = 1e-3 * o0f.abs() + 2.0 ** -8 * o0f.abs() + 1e-5
+        assert bool(((o1 - o0f).abs() <= tol).all()), f"max abs err {float((o1 - o0f).abs().max())}"
