@@ -119,12 +119,21 @@ def test_rebuild_keys(glm):
             assert_bits_equal(c0[b, h, :r0], c1[b, h, :r0], "rows below the rebuilt range")
             assert_bits_equal(c0[b, h, start + S * C:], c1[b, h, start + S * C:], "rows above the sparse region")
     d = ulp_diff_bf16(c0, c1)
-    # MFMA accumulation order vs the oracle's sequential chain: a flipped bf16 rounding of the
-    # pre-RoPE value moves the rotated value by a few ulps at most (|cos|,|sin| <= 1 and a sum)
+    # MFMA accumulates the 160 products in its own order, the oracle as a sequential chain, so a
+    # small fraction of the pre-RoPE bf16 roundings flip by one ulp.  One flipped ulp of x1 or x2
+    # (2^-8 relative) moves a rotated output by at most 2^-8*(|x1|+|x2|) plus its own roundings:
+    # bound |diff| <= 2^-6 * (|x1| + |x2|) per rotation pair, and the flips must stay rare.
     frac = float((d > 0).sum()) / d.numel()
     assert frac < 0.03, f"{frac:.4f} of key values differ"
-    rel = (c0.float() - c1.float()).abs() / (c0.float().abs() + 1e-2)
-    assert float(rel.max()) < 2e-2, f"max relative difference {float(rel.max())}"
+    x = tmp.float().abs()
+    if glm:
+        pair = x[..., 0:64:2] + x[..., 1:64:2]
+        mag = torch.cat((torch.stack((pair, pair), -1).flatten(-2), x[..., 64:]), -1)
+    else:
+        pair = x[..., :64] + x[..., 64:]
+        mag = torch.cat((pair, pair), -1)
+    diff = (c0.float() - c1.float()).abs()[:, :, start:start + S * C]
+    assert bool((diff <= 2.0 ** -6 * mag + 1e-6).all()), f"max excess {float((diff - 2.0 ** -6 * mag).max())}"
 
 
 @pytest.mark.parametrize("bs,Hq,Hkv,kv_len,splits", [(1, 32, 8, 2497, 32), (2, 32, 8, 300, 8), (1, 32, 4, 2560, 32),

@@ -163,17 +163,25 @@ def test_batch_gather_gemm(sk, bs, heads, L, S):
     torch.cuda.synchronize()
     out1 = out1.cpu()
     # only rows of chunks >= cnt are defined
-    tot, bad1, bad2 = 0, 0, 0
+    tot, bad1 = 0, 0
     for b in range(bs):
         for h in range(heads):
             r0 = int(cnts[b * heads + h]) * C
-            d = ulp_diff_bf16(out0[b, h, r0:], out1[b, h, r0:])
-            tot += d.numel(); bad1 += int((d >= 1).sum()); bad2 += int((d > 1).sum())
             # untouched hit rows must stay zero
             assert int(out1[b, h, :r0].abs().sum()) == 0
-    # f32 accumulation order differs (MFMA vs sequential chain): allow <=1 bf16 ulp on <=2% of values
-    assert bad2 == 0, f"{bad2} values differ by more than 1 bf16 ulp"
-    assert bad1 <= 0.02 * tot, f"{bad1}/{tot} values differ by 1 ulp"
+            if r0 == S * C:
+                continue
+            pos = (ids[b, h].to(torch.int64)[:, None] * C + torch.arange(C)[None, :]).flatten()[r0:]
+            sabs = U[b, pos].float().abs() @ SV[b, h].float().abs().T   # sum_j |u_j * sv_j| per output
+            d = ulp_diff_bf16(out0[b, h, r0:], out1[b, h, r0:])
+            adiff = (out0[b, h, r0:].float() - out1[b, h, r0:].float()).abs()
+            # f32 accumulation order differs (hardware MFMA order vs the oracle's model of it): the
+            # two f32 sums differ by at most a few f32 ulps of sum|products| (2^-20 * sabs is generous),
+            # which can flip one bf16 rounding (1 ulp) or, near zero, show up as that absolute error.
+            ok = (d <= 1) | (adiff <= 2.0 ** -20 * sabs)
+            assert bool(ok.all()), f"{int((~ok).sum())} values outside tolerance"
+            tot += d.numel(); bad1 += int((d >= 1).sum())
+    assert bad1 <= 0.02 * tot, f"{bad1}/{tot} values differ by 1 bf16 ulp"
 
 
 def _cos_sin(L, width, g):
