@@ -1,0 +1,280 @@
+"""`ShadowKVCache_CPU` for MI355X: same constructor, methods, attributes and buffer layout as the
+reference's offload cache (/root/reference/models/kv_cache.py:509-1319) so the reference's host
+models (`LLM.layer_compute`, models/base.py:296-341) can drive it unchanged; the decode-time
+methods launch the hand-written gfx950 kernels of libshadowkv_hip.so.
+
+State (per layer l, batch b, KV head h; D = head_dim, C = chunk_size, S = sparse_budget // C):
+  v_cache_cpu   pinned host  [L, bs, kv, max_length // C, C*D]   every V chunk, 2 KiB rows (C=8, D=128)
+  k_/v_cache_buffer  HBM     [L, bs, kv, buf_len, D],  buf_len = budget + 128 + (outlier + local)*C
+        rows [0, prefill_local)            last tokens of the prompt (exact K / V)
+        rows [prefill_local, sparse_start) outlier chunks (exact K / V)
+        rows [sparse_start, sparse_end)    the S selected chunks; slot i holds chunk position_ids[l,b,h,i]
+        rows [sparse_end, buf_len)         tokens generated so far
+  U [L, bs, seq, r], SV [L, bs, kv, D, r]   rank-r factorisation of the pre-RoPE keys (r-contiguous)
+  k_landmark [L, bs, kv, N, D], k_landmark_idx int64 [L, bs, kv, N]   chunk means + their chunk ids
+  position_ids int64 [L, bs, kv, S], offsets int32 [bs*kv*S], cnts int32 [bs*kv], signals int32 [bs*kv]
+
+MI355X-first differences that do not change results:
+  * U / SV / landmarks are created in HBM straight away (288 GB): H2D() only sizes the decode
+    workspaces; the reference parks them on the CPU until H2D() (kv_cache.py:694-696, :1178-1225).
+  * get_retrieval_position_ids is ONE native call (score + softmax + group max + top-k + diff,
+    no [bs,kv,G,N] round trips through torch.max / torch.topk / gather); get_key_cache is one
+    compaction launch + one fused rebuild-RoPE-store launch (no `output` round trip).
+  * the host V stride passed to the mover is the tensor's real stride (max_length // C chunks); the
+    reference passes the prompt length (kv_cache.py:1090), identical whenever prompt == max_length.
+  * top-k membership under exact bf16 ties is defined (lowest landmark slot); torch.topk's is not.
+"""
+import gc
+import math
+
+import torch
+
+from . import tensor_op
+from ._lib import lib, check, ptr, current_stream_handle
+
+
+class ShadowKVCache_CPU:
+    def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
+                 sparse_budget=2048, chunk_size=8, rank=160):
+        if dtype != torch.bfloat16:
+            raise ValueError("ShadowKVCache_CPU supports bfloat16 only (as the reference's kernels do)")
+        self.config = config
+        self.batch_size = batch_size
+        self.max_length = max_length
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.num_attention_heads = config.num_attention_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = config.num_attention_heads // config.num_key_value_heads
+        self.head_dim = config.hidden_size // config.num_attention_heads
+        self.num_layers = config.num_hidden_layers
+
+        self.sparse_budget = int(sparse_budget)
+        self.chunk_size = chunk_size
+        self.rank = rank
+        self.local_chunk = 4
+        self.outlier_chunk = int((self.sparse_budget // 1024) * 24)
+        self.select_sets = self.sparse_budget // self.chunk_size
+        assert self.select_sets * self.chunk_size == self.sparse_budget, \
+            f"({self.select_sets}) * {self.chunk_size} != {self.sparse_budget}"
+
+        L, bs, kv, D, C = self.num_layers, batch_size, self.num_key_value_heads, self.head_dim, chunk_size
+        on_gpu = self.device.type == "cuda"
+        self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype,
+                                       pin_memory=on_gpu)
+        buf_len = self.sparse_budget + 128 + (self.outlier_chunk + self.local_chunk) * C
+        self.k_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)
+        self.v_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)
+
+        self.kv_offset = 0
+        self.prefill = 0
+        self.gen_offset = 0
+        self.prefilled_batch = 0
+        self.k_landmark = None
+        self.k_landmark_idx = None
+        self.U = None
+        self.SV = None
+
+        self.block_num = bs * kv
+        self.offsets = torch.zeros(self.block_num * self.select_sets, device=self.device, dtype=torch.int32)
+        self.cnts = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
+        self.signals = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
+        self._signals_k = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
+        self.position_ids = torch.full((L, bs, kv, self.select_sets), -1, device=self.device, dtype=torch.int64)
+        # kept for signature compatibility with the reference's kernels (unused by the fused path)
+        self.temp = torch.zeros(1, device=self.device, dtype=dtype)
+        self.output = torch.zeros(1, device=self.device, dtype=dtype)
+        self._select_ws = None
+        self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+
+    # ------------------------------------------------------------------ bookkeeping
+    def print_stats(self):
+        print(f"ShadowKV_CPU | sparse budget {self.sparse_budget} | chunk size {self.chunk_size} |rank {self.rank} "
+              f"| cached {self.kv_offset} | local_chunk {self.local_chunk} | outlier_chunk {self.outlier_chunk}")
+
+    def get_kv_len(self):
+        return self.kv_offset
+
+    def clear(self):
+        self.k_cache_buffer.zero_()
+        self.v_cache_buffer.zero_()
+        self.k_landmark = None
+        self.k_landmark_idx = None
+        self.U = None
+        self.SV = None
+        self.kv_offset = 0
+        self.prefill = 0
+        self.gen_offset = 0
+        self.prefill_local = 0
+        self.prefilled_batch = 0
+
+    def H2D(self):
+        """Reference: moves U / SV / landmarks / scratch from CPU tensors to the GPU (kv_cache.py:1178-1225).
+        Here they already live in HBM; this only (re)sizes the selection workspace."""
+        gc.collect()
+        if self.k_landmark is not None and self.device.type == "cuda":
+            n = self.k_landmark.shape[-2]
+            nbytes = lib().skv_select_workspace_bytes(self.block_num, self.num_key_value_groups, n)
+            self._select_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ prefill-side state builders
+    def get_svd(self, new_k_cache, layer_idx):
+        """Rank-r factorisation of the pre-RoPE keys (kv_cache.py:666-737): torch.svd in f32,
+        U[:, :, :r] -> bf16, SV = diag(s) V^T stored [bs, kv, D, r] (r-contiguous for the kernels)."""
+        kv, D = self.num_key_value_heads, self.head_dim
+        if new_k_cache.shape[1] <= 32:   # [bs, kv, seq, D] -> [bs, seq, kv*D]  (same layout test as :683)
+            k = new_k_cache.transpose(1, 2).reshape(new_k_cache.shape[0], -1, kv * D)
+        else:
+            k = new_k_cache
+        bsz, seq = k.shape[0], k.shape[1]
+        if layer_idx == 0 and self.prefilled_batch == 0:
+            self.U = torch.zeros(self.num_layers, self.batch_size, seq, self.rank, device=self.device, dtype=self.dtype)
+            self.SV = torch.zeros(self.num_layers, self.batch_size, kv, D, self.rank, device=self.device,
+                                  dtype=self.dtype)
+        u, s, v = torch.svd(k.float())
+        r = self.rank
+        b0 = self.prefilled_batch
+        self.U[layer_idx][b0:b0 + bsz].copy_(u[:, :, :r].to(self.dtype))
+        sv = torch.matmul(torch.diag_embed(s[:, :r]), v.transpose(1, 2)[:, :r]).to(self.dtype)  # [bs, r, kv*D]
+        self.SV[layer_idx][b0:b0 + bsz].copy_(sv.view(bsz, r, kv, D).permute(0, 2, 3, 1))
+        del u, s, v
+
+    def register_k_landmark(self, k_landmark, k_landmark_idx, layer_idx):
+        n = k_landmark.shape[-2]
+        bsz = k_landmark.shape[0]
+        if layer_idx == 0 and self.prefilled_batch == 0:
+            self.k_landmark = torch.zeros(self.num_layers, self.batch_size, self.num_key_value_heads, n, self.head_dim,
+                                          device=self.device, dtype=self.dtype)
+            self.k_landmark_idx = torch.zeros(self.num_layers, self.batch_size, self.num_key_value_heads, n,
+                                              device=self.device, dtype=torch.long)
+        b0 = self.prefilled_batch
+        self.k_landmark[layer_idx][b0:b0 + bsz].copy_(k_landmark)
+        self.k_landmark_idx[layer_idx][b0:b0 + bsz].copy_(k_landmark_idx)
+
+    def _score_landmarks_torch(self, layer_idx, b0, bsz, last_q):
+        """Initial selection at prefill time, in torch ops exactly as the reference does it
+        (kv_cache.py:926-945): einsum / sqrt(128) -> f32 softmax -> bf16 -> max over the group -> topk."""
+        kv, G, D = self.num_key_value_heads, self.num_key_value_groups, self.head_dim
+        attn = torch.einsum("bhgd,bhcd->bhgc", last_q.view(-1, kv, G, D),
+                            self.k_landmark[layer_idx][b0:b0 + bsz].to(last_q.device)) / math.sqrt(128)
+        attn = torch.nn.functional.softmax(attn, dim=-1, dtype=torch.float32).to(self.dtype)
+        attn, _ = torch.max(attn, dim=-2)
+        top = torch.topk(attn, k=self.select_sets, dim=-1).indices
+        return self.k_landmark_idx[layer_idx][b0:b0 + bsz].to(last_q.device).gather(dim=-1, index=top)
+
+    def prefill_kv_cache(self, new_v_cache, layer_idx, key_states_roped, last_query_states=None):
+        """Builds every decode-time input of one layer from the prompt's V and post-RoPE K
+        (kv_cache.py:788-980): V chunks to pinned host memory, local rows and outlier chunks to the
+        buffers, landmarks (chunk means of the non-outlier chunks), the initial selection with the last
+        query and the initial fill of the sparse region with exact K / V."""
+        bsz, kv, incoming, D = new_v_cache.shape
+        C, S = self.chunk_size, self.select_sets
+        b0 = self.prefilled_batch
+        self.prefill = incoming
+        n_chunks_all = incoming // C
+        self.max_ctx_chunks_len = n_chunks_all * C
+        self.v_cache_cpu[layer_idx][b0:b0 + bsz, :, :n_chunks_all].copy_(
+            new_v_cache[:, :, :self.max_ctx_chunks_len].reshape(bsz, kv, n_chunks_all, C * D), non_blocking=True)
+
+        self.chunks = n_chunks_all - self.local_chunk
+        self.chunks -= self.chunks % 8
+        ctx = self.chunks * C
+        self.prefill_local = incoming - ctx
+        kbuf, vbuf = self.k_cache_buffer[layer_idx][b0:b0 + bsz], self.v_cache_buffer[layer_idx][b0:b0 + bsz]
+        kbuf[:, :, :self.prefill_local].copy_(key_states_roped[:, :, -self.prefill_local:])
+        vbuf[:, :, :self.prefill_local].copy_(new_v_cache[:, :, -self.prefill_local:])
+
+        k_ctx = key_states_roped[:, :, :ctx].view(bsz, kv, self.chunks, C, D)
+        v_ctx = new_v_cache[:, :, :ctx].view(bsz, kv, self.chunks, C, D)
+        means = k_ctx.mean(dim=-2)                                             # landmark candidates
+        cos_sim = torch.nn.functional.cosine_similarity(means.unsqueeze(3).expand(-1, -1, -1, C, -1), k_ctx, dim=-1)
+        outlier_idx = cos_sim.min(dim=-1).values.topk(self.outlier_chunk, largest=False).indices
+        sel = outlier_idx[..., None, None].expand(-1, -1, -1, C, D)
+        n_out = self.outlier_chunk * C
+        self.sparse_start = self.prefill_local + n_out
+        self.sparse_end = self.sparse_start + self.sparse_budget
+        self.kernel_offset = self.sparse_start * D
+        self.kernel_stride = self.v_cache_buffer[layer_idx].shape[-2] * D
+        kbuf[:, :, self.prefill_local:self.sparse_start].copy_(k_ctx.gather(2, sel).view(bsz, kv, n_out, D))
+        vbuf[:, :, self.prefill_local:self.sparse_start].copy_(v_ctx.gather(2, sel).view(bsz, kv, n_out, D))
+
+        keep = torch.ones(bsz, kv, self.chunks, dtype=torch.bool, device=key_states_roped.device)
+        keep.scatter_(-1, outlier_idx, False)
+        rest_idx = torch.arange(self.chunks, device=key_states_roped.device).expand(bsz, kv, -1) \
+            .masked_select(keep).view(bsz, kv, -1)
+        self.register_k_landmark(means.gather(2, rest_idx.unsqueeze(-1).expand(-1, -1, -1, D)), rest_idx, layer_idx)
+
+        chosen = self._score_landmarks_torch(layer_idx, b0, bsz, last_query_states)
+        self.position_ids[layer_idx][b0:b0 + bsz].copy_(chosen)
+        pos = self.position_ids[layer_idx][b0:b0 + bsz]
+        assert pos.max() < self.chunks, f"position_ids exceed the max_length {pos.max()}"
+        assert pos.min() >= 0, f"position_ids exceed the min_length {pos.min()}"
+        tok = (chosen.unsqueeze(-1) * C + torch.arange(C, device=chosen.device)).view(bsz, kv, -1)
+        tok = tok.unsqueeze(-1).expand(-1, -1, -1, D)
+        vbuf[:, :, self.sparse_start:self.sparse_end].copy_(new_v_cache.gather(-2, tok), non_blocking=True)
+        kbuf[:, :, self.sparse_start:self.sparse_end].copy_(key_states_roped.gather(-2, tok), non_blocking=True)
+
+        if layer_idx == self.num_layers - 1:
+            assert self.sparse_budget < incoming
+            self.prefilled_batch += bsz
+            if self.prefilled_batch == self.batch_size:
+                self.kv_offset += incoming
+                assert not torch.any(self.position_ids == -1), \
+                    f"The cache for offloading is not built correctly, {self.position_ids}"
+
+    # ------------------------------------------------------------------ decode (native)
+    def _gen_rows(self, layer_idx):
+        return self.gen_offset if layer_idx == self.num_layers - 1 else self.gen_offset + self.incoming_q_len
+
+    def get_retrieval_position_ids(self, layer_idx, query_states):
+        """Selects this step's chunks and diffs them against the resident set (kv_cache.py:983-1057).
+        Returns position_ids[layer_idx] (reordered in place: hits by old slot, then misses by id);
+        self.offsets / self.cnts are the mover's inputs."""
+        self.incoming_q_len = query_states.shape[-2]
+        if self.incoming_q_len != 1:
+            raise ValueError("decode-time selection expects q_len == 1 (the reference's top-k over "
+                             "view(bs, kv, G, -1) is only meaningful for q_len == 1, kv_cache.py:1023-1035)")
+        lm = self.k_landmark[layer_idx]
+        n = lm.shape[-2]
+        if self._select_ws is None:
+            self.H2D()
+        q = query_states if query_states.is_contiguous() else query_states.contiguous()
+        check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
+                                      ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self.cnts),
+                                      ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
+                                      self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
+              "get_retrieval_position_ids")
+        return self.position_ids[layer_idx]
+
+    def get_value_cache(self, layer_idx, position_ids):
+        """Hit chunks compacted in place, miss chunks fetched from pinned host memory into the sparse
+        region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream)."""
+        vhost = self.v_cache_cpu[layer_idx]
+        vbuf = self.v_cache_buffer[layer_idx]
+        check(lib().skv_move_chunks(ptr(vhost), ptr(vbuf), ptr(self.offsets), ptr(self.cnts), ptr(self.signals),
+                                    vhost.stride(1), vbuf.stride(1), self.sparse_start * self.head_dim,
+                                    self.block_num, self.select_sets, current_stream_handle()), "get_value_cache")
+        return vbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+
+    def get_key_cache(self, layer_idx, position_ids, rope_func, cos_sin_cache):
+        """Hit chunks compacted in place, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
+        region (kv_cache.py:1108-1176).  `rope_func` is unused, as in the reference."""
+        kbuf = self.k_cache_buffer[layer_idx]
+        check(lib().skv_move_chunks(0, ptr(kbuf), ptr(self.offsets), ptr(self.cnts), ptr(self._signals_k), 0,
+                                    kbuf.stride(1), self.sparse_start * self.head_dim, self.block_num,
+                                    self.select_sets, current_stream_handle()), "get_key_cache/compaction")
+        tensor_op.rebuild_keys(self.U[layer_idx], self.SV[layer_idx], cos_sin_cache, position_ids, self.cnts, kbuf,
+                               self.sparse_start, self.chunk_size)
+        return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+
+    def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
+        """Appends the new token's K / V after the sparse region (kv_cache.py:1227-1271); rows past
+        the end of the buffer are dropped exactly as the reference's zero-length slice does."""
+        incoming = new_k_cache.shape[-2]
+        lo = self.sparse_end + self.gen_offset
+        self.v_cache_buffer[layer_idx][:, :, lo:lo + incoming].copy_(new_v_cache, non_blocking=True)
+        self.k_cache_buffer[layer_idx][:, :, lo:lo + incoming].copy_(new_k_cache, non_blocking=True)
+        if layer_idx == self.num_layers - 1:
+            self.kv_offset += incoming
+            self.gen_offset += incoming

@@ -1,0 +1,183 @@
+"""Tensor-op surface the reference's host models import (`/root/reference/models/tensor_op.py`),
+re-implemented on PyTorch-ROCm ops + libshadowkv_hip.so.
+
+Names, argument order and return values follow the reference so `models/llama.py` /
+`models/base.py`-style host code can import from here unchanged:
+  layer_norm, apply_rotary_pos_emb, apply_rotary_pos_emb_single, apply_rotary_pos_emb_cuda,
+  apply_rotary_pos_emb_cuda_push_cache, batch_gather_gemm_rotary_pos_emb_cuda, sample_token, ...
+plus what replaces third-party CUDA packages on this path:
+  sparse_attention_decode  (flash_attn_with_kvcache at base.py:341, q_len == 1)
+  silu_and_mul, rotary_embedding_neox  (vllm._custom_ops at llama.py:296,421)
+`minference_prefill_kernel` (MInference sparse prefill) is outside the decode path and raises.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from ._lib import lib, check, ptr, current_stream_handle
+from .kernels import shadowkv
+
+
+# ---------------------------------------------------------------------------- norms / activations
+def layer_norm(hidden_states, eps, w):
+    """RMSNorm (reference: flashinfer.norm.rmsnorm, tensor_op.py:34-39; the commented-out torch
+    version at :41-51 is the spec: f32 variance, normalise, cast back, scale by w)."""
+    shape = hidden_states.shape
+    out = F.rms_norm(hidden_states.reshape(-1, shape[-1]), (shape[-1],), w, eps)
+    return out.view(shape)
+
+
+def silu_and_mul(out, x):
+    """out = silu(x[..., :d]) * x[..., d:]  (vllm._custom_ops.silu_and_mul, llama.py:421)."""
+    d = x.shape[-1] // 2
+    torch.mul(F.silu(x[..., :d]), x[..., d:], out=out)
+    return out
+
+
+# ---------------------------------------------------------------------------- RoPE (pure torch, tensor_op.py:127-151)
+def rotate_half(x):
+    half = x.shape[-1] // 2
+    return torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin, position_ids):
+    cos = cos[position_ids].unsqueeze(1)
+    sin = sin[position_ids].unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+def apply_rotary_pos_emb_single(q, cos, sin, position_ids, unsqueeze_dim=1):
+    if position_ids.dim() == 3:  # [bs, heads, seq] -> one position per (b, h, s)
+        flat = position_ids.reshape(-1, position_ids.size(-1))
+        return (q * cos[flat]) + (rotate_half(q) * sin[flat])
+    cos = cos[position_ids].unsqueeze(unsqueeze_dim)
+    sin = sin[position_ids].unsqueeze(unsqueeze_dim)
+    return (q * cos) + (rotate_half(q) * sin)
+
+
+# ---------------------------------------------------------------------------- RoPE (native, tensor_op.py:154-238)
+def apply_rotary_pos_emb_cuda(x, cos_sin, position_ids):
+    bs, heads, seq_len, dim = x.shape
+    out = torch.empty_like(x)
+    shadowkv.apply_rotary_pos_emb_new(x, cos_sin, position_ids, out, bs, heads, seq_len, dim,
+                                      x.stride(0), x.stride(1), x.stride(2), x.stride(3), cos_sin.stride(0),
+                                      position_ids.stride(0), position_ids.stride(1), position_ids.stride(2),
+                                      dim // 2)
+    return out
+
+
+def apply_rotary_pos_emb_cuda_push_cache(x, cos_sin, position_ids, chunk_size, cache, sparse_start, sparse_end, cnts):
+    bs, heads, seq_len, dim = x.shape
+    width = cos_sin.shape[-1]
+    if width == 128:
+        fn = shadowkv.apply_rotary_pos_emb_push_cache_opt
+    elif width == 64:
+        fn = shadowkv.apply_rotary_pos_emb_push_cache_opt_glm
+    else:
+        raise ValueError(f"Invalid cos_sin shape {cos_sin.shape}")
+    fn(x, cos_sin, position_ids, cache, cnts, bs, heads, seq_len, dim,
+       x.stride(0), x.stride(1), x.stride(2), x.stride(3), cos_sin.stride(0),
+       position_ids.stride(0), position_ids.stride(1), position_ids.stride(2),
+       cache.stride(0), cache.stride(1), cache.stride(2), int(sparse_start), int(sparse_end), dim // 2,
+       int(chunk_size))
+    return cache
+
+
+def batch_gather_gemm_rotary_pos_emb_cuda(a, b, cos_sin, position_ids, output, chunk_size, cache, sparse_start,
+                                          sparse_end, cnts):
+    """Two-launch form with the reference's signature (gather-GEMM into `output`, then RoPE-and-push).
+    The decode path of ShadowKVCache_CPU uses the fused single launch (`rebuild_keys`) instead."""
+    bs, seq_len, rank = a.shape
+    _, heads, head_dim, _ = b.shape
+    max_seq_len = cos_sin.shape[0]
+    num_chunks = position_ids.shape[-1]
+    pid32 = position_ids.to(torch.int32).contiguous()
+    shadowkv.batch_gather_gemm(a.contiguous(), b.contiguous(), cos_sin, cos_sin, pid32, output, bs, heads, seq_len,
+                               head_dim, rank, num_chunks * chunk_size, max_seq_len, chunk_size, cnts)
+    return apply_rotary_pos_emb_cuda_push_cache(output, cos_sin, pid32, chunk_size, cache, sparse_start, sparse_end,
+                                                cnts)
+
+
+def rebuild_keys(U, SV, cos_sin, position_ids, cnts, cache, sparse_start, chunk_size):
+    """Fused K rebuild: cache[b,h,sparse_start+i] = RoPE(bf16(U[b,pos(i)].SV[b,h]^T)) for chunks >= cnts.
+    U [bs, seq, r], SV [bs, heads, 128, r], position_ids int64 [bs, heads, S], cache [bs, heads, rows, 128]."""
+    bs, seq_len, rank = U.shape
+    heads, head_dim = SV.shape[1], SV.shape[2]
+    width = cos_sin.shape[-1]
+    if width not in (128, 64):
+        raise ValueError(f"Invalid cos_sin shape {cos_sin.shape}")
+    check(lib().skv_rebuild_keys(ptr(U), ptr(SV), ptr(cos_sin), ptr(position_ids), ptr(cnts), ptr(cache), bs, heads,
+                                 seq_len, head_dim, rank, position_ids.shape[-1], int(chunk_size), cos_sin.stride(0),
+                                 cache.stride(0), cache.stride(1), cache.stride(2), int(sparse_start),
+                                 1 if width == 128 else 2, current_stream_handle()), "rebuild_keys")
+    return cache
+
+
+# ---------------------------------------------------------------------------- attention
+_attn_ws = {}
+
+
+def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, splits=None, out=None):
+    """softmax(q K^T / sqrt(D)) V for q_len == 1 over the first kv_len rows of the cache views.
+    q [bs, Hq, 1, D] or [bs, Hq, D]; k_cache / v_cache [bs, Hkv, rows, D] views of contiguous
+    [bs, Hkv, buf_rows, D] buffers (what get_key_cache / get_value_cache return).  Returns
+    [bs, 1, Hq, D] like flash_attn_with_kvcache's output for q [bs, 1, Hq, D]."""
+    bs, Hq = q.shape[0], q.shape[1]
+    D = q.shape[-1]
+    Hkv = k_cache.shape[1]
+    if kv_len is None:
+        kv_len = k_cache.shape[2]
+    if k_cache.stride(3) != 1 or k_cache.stride(2) != D or k_cache.stride(0) != Hkv * k_cache.stride(1) \
+            or k_cache.stride() != v_cache.stride():
+        raise ValueError("k/v cache views must be row-contiguous slices of [bs, Hkv, rows, D] buffers")
+    if not q.is_contiguous():
+        q = q.contiguous()
+    if splits is None:
+        splits = max(1, min(64, 256 // max(1, bs * Hkv)))
+    key = (q.device.index, bs, Hq, splits)
+    ws = _attn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=q.device)
+        _attn_ws[key] = ws
+    if out is None:
+        out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
+    check(lib().skv_sparse_attention(ptr(q), ptr(k_cache), ptr(v_cache), ptr(out), ptr(ws), ptr(kv_len_dev),
+                                     int(kv_len), k_cache.stride(1), bs, Hq, Hkv, D, splits, 1.0 / math.sqrt(D),
+                                     current_stream_handle()), "sparse_attention")
+    return out
+
+
+def minference_prefill_kernel(*args, **kwargs):
+    raise NotImplementedError("MInference sparse prefill is outside the decode hot path (SURVEY.md section 2a)")
+
+
+# ---------------------------------------------------------------------------- sampling (tensor_op.py:242-297)
+def top_k_top_p_filter(logits, top_k=0, top_p=0.0):
+    if top_k > 0:
+        kth = torch.topk(logits, min(top_k, logits.size(-1)))[0][:, [-1]]
+        logits[logits < kth] = float("-inf")
+    if top_p > 0.0:
+        sorted_logits, sorted_idx = torch.sort(logits, descending=True)
+        remove = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1) > top_p
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = 0
+        logits[remove.scatter(1, sorted_idx, remove)] = float("-inf")
+    return logits
+
+
+def norm_logits(logits, temperature=0.6, top_k=-1, top_p=0.9):
+    assert logits.dim() == 2
+    if temperature != 1.0:
+        logits = logits / temperature
+    return F.softmax(top_k_top_p_filter(logits, top_k=top_k, top_p=top_p), dim=-1)
+
+
+def sample(probs, num_samples=1):
+    return torch.multinomial(probs, num_samples=num_samples, replacement=True)
+
+
+def sample_token(logits, temperature=0, top_k=50, top_p=0.9):
+    if temperature == 0.0:
+        return logits.argmax(dim=-1, keepdim=True)
+    return sample(norm_logits(logits, temperature=temperature, top_p=top_p, top_k=top_k))

@@ -1,0 +1,90 @@
+"""CPU: the state builders of shadowkv_amd.kv_cache.ShadowKVCache_CPU (prefill half, torch ops) against
+fixtures produced by the reference's ShadowKVCache_CPU.get_svd / prefill_kv_cache
+(/root/reference/models/kv_cache.py:666-980) on the same seeded inputs."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as G
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(t):
+    a = t.contiguous().view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module", params=list(G.CASES))
+def built(request):
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    case = request.param
+    c, inp = G.CASES[case], G.make_inputs(case)
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    cache.get_svd(inp["k_pre"], 0)
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+    cache.prefill_kv_cache(inp["v"], 0, k_roped, inp["q_last"])
+    return case, cache, np.load(os.path.join(GOLD, f"{case}.npz")), inp
+
+
+def test_layout_constants(built):
+    case, cache, z, _ = built
+    meta = z["cpu_meta"]
+    got = [cache.chunks, cache.prefill_local, cache.sparse_start, cache.sparse_end, cache.select_sets,
+           cache.outlier_chunk, cache.max_ctx_chunks_len, cache.kernel_offset, cache.kernel_stride, cache.kv_offset]
+    assert got == meta.tolist()
+
+
+def test_svd_factors(built):
+    _, cache, z, _ = built
+    assert np.array_equal(sha(cache.U[0]), z["h_cpu_U"])
+    assert np.array_equal(sha(cache.SV[0]), z["h_cpu_SV"])
+
+
+def test_landmarks_and_initial_selection(built):
+    _, cache, z, _ = built
+    assert np.array_equal(cache.k_landmark_idx[0].numpy(), z["cpu_lm_idx"])
+    assert np.array_equal(sha(cache.k_landmark[0]), z["h_cpu_lm"])
+    assert np.array_equal(cache.position_ids[0].numpy(), z["cpu_pos0"])
+
+
+def test_buffers_and_host_table(built):
+    case, cache, z, inp = built
+    assert np.array_equal(sha(cache.k_cache_buffer[0][:, :, :cache.sparse_end]), z["h_cpu_kbuf"])
+    assert np.array_equal(sha(cache.v_cache_buffer[0][:, :, :cache.sparse_end]), z["h_cpu_vbuf"])
+    nch = cache.max_ctx_chunks_len // cache.chunk_size
+    rows = cache.v_cache_cpu[0][:, :, [0, 1, nch // 2, nch - 1]]
+    assert np.array_equal(rows.contiguous().view(torch.int16).numpy().view(np.uint16), z["cpu_vhost_rows"])
+    # invariant the decode path relies on: slot i of the sparse region holds chunk position_ids[i]
+    C, D = cache.chunk_size, cache.head_dim
+    v = inp["v"][0]
+    for h in range(cache.num_key_value_heads):
+        ids = cache.position_ids[0][0, h]
+        want = v[h].view(-1, C, D)[ids].reshape(-1, D)
+        assert torch.equal(cache.v_cache_buffer[0][0, h, cache.sparse_start:cache.sparse_end], want)
+
+
+def test_update_and_bookkeeping(built):
+    _, cache, _, _ = built
+    k = torch.ones(1, cache.num_key_value_heads, 1, 128, dtype=torch.bfloat16)
+    off0, kv0 = cache.gen_offset, cache.kv_offset
+    cache.update_kv_cache(k, 2 * k, 0)
+    assert cache.gen_offset == off0 + 1 and cache.get_kv_len() == kv0 + 1
+    assert torch.equal(cache.k_cache_buffer[0][:, :, cache.sparse_end + off0], k[:, :, 0])
+    assert torch.equal(cache.v_cache_buffer[0][:, :, cache.sparse_end + off0], 2 * k[:, :, 0])
+    # rows past the slack are dropped silently, as in the reference (kv_cache.py:1255-1265)
+    cache.gen_offset = cache.k_cache_buffer.shape[-2] - cache.sparse_end
+    cache.update_kv_cache(k, k, 0)
+
+
+def test_decode_methods_fail_loudly_without_gpu(built):
+    """No CPU fallback on the product path: on a box without a GPU the native launch must raise."""
+    _, cache, _, inp = built
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        cache.get_retrieval_position_ids(0, inp["q_steps"][0])
