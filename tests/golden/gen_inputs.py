@@ -16,7 +16,7 @@ CASES = {
                         chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=1234),
     "llama_cpu_b1024": dict(layers=1, q_heads=32, kv_heads=8, head_dim=128, L=2200, budget=1024,
                             chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=4321),
-    "glm_small": dict(layers=1, q_heads=32, kv_heads=2, head_dim=128, L=2048, budget=256,
+    "glm_small": dict(layers=1, q_heads=32, kv_heads=4, head_dim=128, L=2048, budget=256,
                       chunk=8, rank=160, rope_theta=10000.0, glm=True, seed=777),
 }
 

@@ -1,0 +1,128 @@
+"""GPU: ShadowKVCache_CPU driven exactly as LLM.layer_compute drives it (models/base.py:315-341) for
+several decode steps, against a CPU mirror advanced by the oracle from the same starting state."""
+import math
+
+import pytest
+import torch
+
+import gen_inputs as G
+import oracle
+from util import ALPHA, assert_bits_equal, ulp_diff_bf16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(case):
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    c, inp = G.CASES[case], G.make_inputs(case)
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=DEV, dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    k_pre = inp["k_pre"].to(DEV)
+    cache.get_svd(k_pre, 0)
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0)).to(DEV)
+    cache.prefill_kv_cache(inp["v"].to(DEV), 0, k_roped, inp["q_last"].to(DEV))
+    cache.H2D()
+    torch.cuda.synchronize()
+    return cache, c, inp
+
+
+@pytest.mark.parametrize("case", ["llama_small", "llama_cpu_b1024", "glm_small"])
+def test_decode_steps_match_oracle(case):
+    from shadowkv_amd import tensor_op
+    cache, c, inp = _build(case)
+    kv, Hq, D, C, S = c["kv_heads"], c["q_heads"], c["head_dim"], c["chunk"], cache.select_sets
+    Gq = Hq // kv
+    cs_dev = inp["cos_sin"].to(DEV)
+    # CPU mirror of the state the GPU starts from
+    lm = cache.k_landmark[0][0].cpu().contiguous(); lm_idx = cache.k_landmark_idx[0][0].cpu().contiguous()
+    N = lm.shape[1]; T = (N + 255) // 256
+    U = cache.U[0].cpu().contiguous(); SV = cache.SV[0].cpu().contiguous()
+    pos = cache.position_ids[0][0].cpu().clone()
+    kbuf = cache.k_cache_buffer[0][0].cpu().clone(); vbuf = cache.v_cache_buffer[0][0].cpu().clone()
+    vhost = cache.v_cache_cpu[0][0].clone()
+    rows = kbuf.shape[1]
+    hit_rates = []
+    for t in range(inp["q_steps"].shape[0]):
+        q = inp["q_steps"][t]                                           # [1, Hq, 1, D]
+        # ---------------- GPU, in the reference's call order with its two-stream overlap
+        qd = q.to(DEV)
+        knew = torch.randn(1, kv, 1, D, generator=torch.Generator().manual_seed(t)).bfloat16()
+        vnew = torch.randn(1, kv, 1, D, generator=torch.Generator().manual_seed(100 + t)).bfloat16()
+        cache.update_kv_cache(knew.to(DEV), vnew.to(DEV), 0)           # single layer == last layer: offsets advance
+        position_ids = cache.get_retrieval_position_ids(layer_idx=0, query_states=qd)
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(cache.copy_stream):
+            cache.copy_stream.wait_stream(cur)
+            v_view = cache.get_value_cache(0, position_ids)
+        k_view = cache.get_key_cache(layer_idx=0, position_ids=position_ids, rope_func=None, cos_sin_cache=cs_dev)
+        cur.wait_stream(cache.copy_stream)
+        attn = tensor_op.sparse_attention_decode(qd, k_view, v_view)
+        torch.cuda.synchronize()
+        # ---------------- CPU mirror through the oracle
+        gen_row = cache.sparse_end + t
+        kbuf[:, gen_row] = knew[0, :, 0]; vbuf[:, gen_row] = vnew[0, :, 0]
+        Dm = torch.zeros(kv, Gq, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
+        oracle.batch_gemm_softmax(q.view(kv, Gq, D).contiguous(), lm, Dm, torch.zeros(kv, T, Gq), torch.zeros(kv, T, Gq),
+                                  P, kv, Gq, N, D, ALPHA)
+        sel = oracle.group_max_topk(P, lm_idx, kv, Gq, N, S)
+        off = torch.zeros(kv, S, dtype=torch.int32); cnt = torch.zeros(kv, dtype=torch.int32)
+        oracle.reorder_keys_and_compute_offsets(pos, sel, off, cnt, 1, kv, S)
+        assert torch.equal(pos, cache.position_ids[0][0].cpu()), f"step {t}: position_ids"
+        assert torch.equal(off.flatten(), cache.offsets.cpu()), f"step {t}: offsets"
+        assert torch.equal(cnt, cache.cnts.cpu()), f"step {t}: cnts"
+        hit_rates.append(float(cnt.sum()) / (kv * S))
+        oracle.gather_copy_with_offsets(vhost, vbuf, None, off, cnt, None, 1, kv, vhost.stride(0), S * C * D,
+                                        cache.sparse_start * D, rows * D, S)
+        assert_bits_equal(vbuf, cache.v_cache_buffer[0][0], f"step {t}: V buffer")
+        oracle.gather_copy_d2d_with_offsets(kbuf, off, cnt, 1, kv, S * C * D, cache.sparse_start * D, rows * D, S)
+        pre = torch.zeros(1, kv, S * C, D, dtype=torch.bfloat16)
+        ids32 = pos.to(torch.int32).view(1, kv, S).contiguous()
+        oracle.batch_gather_gemm(U, SV, None, None, ids32, pre, 1, kv, U.shape[1], D, c["rank"], S * C, 0, C, cnt)
+        kb4 = kbuf.view(1, kv, rows, D)
+        cs = inp["cos_sin"]
+        ints = (1, kv, S * C, D, pre.stride(0), pre.stride(1), pre.stride(2), 1, cs.stride(0), ids32.stride(0),
+                ids32.stride(1), ids32.stride(2), kb4.stride(0), kb4.stride(1), kb4.stride(2), cache.sparse_start,
+                cache.sparse_end, 64, C)
+        (oracle.apply_rotary_pos_emb_push_cache_opt_glm if c["glm"] else oracle.apply_rotary_pos_emb_push_cache_opt)(
+            pre, cs, ids32, kb4, cnt, *ints)
+        kgpu = cache.k_cache_buffer[0][0].cpu()
+        d = ulp_diff_bf16(kbuf, kgpu)
+        assert float((d > 0).sum()) / d.numel() < 0.03, f"step {t}: K buffer"
+        assert float((kbuf.float() - kgpu.float()).abs().max()) < 0.25, f"step {t}: K buffer max abs"
+        # hit rows and everything outside the rebuilt range must be bit-identical
+        for h in range(kv):
+            r0 = cache.sparse_start + int(cnt[h]) * C
+            assert_bits_equal(kbuf[h, :r0], kgpu[h, :r0], f"step {t}: K rows below the rebuilt range")
+            assert_bits_equal(kbuf[h, cache.sparse_end:], kgpu[h, cache.sparse_end:], f"step {t}: generated rows")
+        kbuf.copy_(kgpu)                                                # keep the mirror on the device's K bits
+        # returned views: [:, :, :sparse_end + gen]
+        assert k_view.shape[2] == cache.sparse_end + t + 1 and v_view.shape[2] == k_view.shape[2]
+        _, a32 = oracle.sparse_attention(q.view(1, Hq, D).contiguous(), kgpu.unsqueeze(0).contiguous(),
+                                         vbuf.unsqueeze(0).contiguous(), k_view.shape[2], 1 / math.sqrt(D))
+        got = attn.view(1, Hq, D).cpu().float()
+        tol = 1e-3 * a32.abs() + 2.0 ** -8 * a32.abs() + 1e-5
+        assert bool(((got - a32).abs() <= tol).all()), f"step {t}: attention max err {float((got - a32).abs().max())}"
+    assert int(cache.signals.abs().sum()) == 0 and int(cache._signals_k.abs().sum()) == 0
+    from shadowkv_amd._lib import lib
+    assert lib().skv_move_timeout_flag() == 0
+    assert max(hit_rates) > 0.0   # the random-walk queries do re-select resident chunks
+
+
+def test_legacy_two_launch_key_path_equals_fused():
+    """tensor_op.batch_gather_gemm_rotary_pos_emb_cuda (reference signature, two launches through an
+    `output` buffer) and the fused rebuild must write identical bits: same MFMA order, same roundings."""
+    from shadowkv_amd import tensor_op
+    cache, c, inp = _build("llama_small")
+    kv, D, C, S = c["kv_heads"], c["head_dim"], c["chunk"], cache.select_sets
+    cs = inp["cos_sin"].to(DEV)
+    cache.update_kv_cache(torch.zeros(1, kv, 1, D, dtype=torch.bfloat16, device=DEV),
+                          torch.zeros(1, kv, 1, D, dtype=torch.bfloat16, device=DEV), 0)
+    pos = cache.get_retrieval_position_ids(layer_idx=0, query_states=inp["q_steps"][0].to(DEV))
+    k1 = cache.k_cache_buffer[0].clone(); k2 = cache.k_cache_buffer[0].clone()
+    tensor_op.rebuild_keys(cache.U[0], cache.SV[0], cs, pos, cache.cnts, k1, cache.sparse_start, C)
+    out = torch.zeros(1, kv, S * C, D, dtype=torch.bfloat16, device=DEV)
+    tensor_op.batch_gather_gemm_rotary_pos_emb_cuda(cache.U[0], cache.SV[0], cs, pos, out, C, k2, cache.sparse_start,
+                                                    cache.sparse_end, cache.cnts)
+    torch.cuda.synchronize()
+    assert_bits_equal(k1, k2, "fused vs two-launch K rebuild")
