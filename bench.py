@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""ShadowKV decode throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One "step" = one decoded token: the reference's timed loop body (models/base.py:628-635):
+inference(next_token) over all layers -> sample_token(temperature 0.6) -> host read of the token.
+Workload (configs[1] of BASELINE.json): Llama-3.1-8B shapes, 122K-token context (124,928), sparse_budget 2048,
+rank 160, chunk 8, one sequence per GPU.  N > 1 = N independent replicas (one process / GPU / sequence,
+no collective on the decode path); aggregate tokens/s = N*K / max-over-ranks time.
+Weights and context are synthetic (no checkpoints / datasets offline): random bf16 weights in the named
+shapes, context state from shadowkv_amd.llama.build_synthetic_context, per-layer query random walk.
+
+Prints ONE JSON line on rank 0 (metric / roofline / cpu_baseline: see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (model config attr, context tokens, sparse budget)
+    "llama31_122k": ("LLAMA_3_1_8B", 122 * 1024, 2048),
+    "llama3_1048k_131072": ("LLAMA_3_8B_1048K", 131072, 2048),
+    "glm4_200k": ("GLM_4_9B_1M", 200 * 1024, 2048),
+    "llama31_4k": ("LLAMA_3_1_8B", 4104, 256),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def aggregate_throughput(tokens_per_rank, elapsed_per_rank):
+    """Whole-job tokens/s of independent replicas: sum of tokens / slowest rank's time."""
+    return float(sum(tokens_per_rank)) / max(elapsed_per_rank)
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Best effort: run this process (and allocate its pinned V table) on the NUMA node of its GPU."""
+    try:
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        dom = torch.cuda.get_device_properties(local_rank).pci_domain_id
+        dev = torch.cuda.get_device_properties(local_rank).pci_device_id
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/numa_node"
+        node = int(open(path).read().strip())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, set(cpus) & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+        return node
+    except Exception:
+        return None
+
+
+def measure_score_kernel(model, iters=3):
+    """HIP-event timing of the dominant hand-written kernel (landmark scan, skv_score_tile_kernel) on
+    torch's current stream, cycling over all layers' landmark tables (1 GB >> Infinity Cache)."""
+    from shadowkv_amd import _lib
+    cache = model.kv_cache
+    B, G = cache.block_num, cache.num_key_value_groups
+    N = cache.k_landmark.shape[-2]
+    T = (N + 255) // 256
+    dev = model.device
+    q = torch.randn(B, G, 128, device=dev).to(model.dtype)
+    D = torch.empty(B, G, N, device=dev, dtype=model.dtype)
+    pm = torch.empty(B, T, G, device=dev)
+    ps = torch.empty(B, T, G, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = _lib.lib()
+
+    def run_all():
+        for l in range(model.num_layers):
+            _lib.check(L.skv_score_landmarks(q.data_ptr(), cache.k_landmark[l].data_ptr(), D.data_ptr(), pm.data_ptr(),
+                                             ps.data_ptr(), B, G, N, 1.0 / math.sqrt(128), st), "score")
+    run_all()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run_all()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (iters * model.num_layers)
+    alg_bytes = B * N * 128 * 2            # landmark rows read once (SURVEY.md 8d "landmark read")
+    return dict(kernel="skv_score_tile_kernel", us_per_launch=us, algorithmic_bytes=alg_bytes,
+                gbs=alg_bytes / us * 1e-3)
+
+
+def measure_path_only(model, walk, steps=8):
+    """Decode-path kernels alone (select -> V move || K move + rebuild -> attention), dense layers excluded."""
+    from shadowkv_amd import tensor_op
+    cache = model.kv_cache
+    cur = torch.cuda.current_stream()
+    hits = torch.zeros((), device=model.device, dtype=torch.float32)
+
+    def one_token():
+        nonlocal hits
+        walk.advance()
+        for l in range(model.num_layers):
+            q = walk.qb[l]
+            ids = cache.get_retrieval_position_ids(layer_idx=l, query_states=q)
+            hits += cache.cnts.sum()
+            with torch.cuda.stream(cache.copy_stream):
+                cache.copy_stream.wait_stream(cur)
+                v = cache.get_value_cache(l, ids)
+            k = cache.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=model.cos_sin_cache)
+            cur.wait_stream(cache.copy_stream)
+            tensor_op.sparse_attention_decode(q, k, v)
+    one_token()
+    torch.cuda.synchronize()
+    hits.zero_()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_token()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    hit_rate = float(hits) / (steps * model.num_layers * cache.block_num * cache.select_sets)
+    return dt * 1e3, hit_rate
+
+
+def cpu_baseline(model, walk, sample_layers=2, sample_steps=2):
+    """The oracle (CPU restatement, OpenMP) timed on this box's host cores for the ShadowKV path of
+    `sample_layers` layers x `sample_steps` tokens, plus torch-CPU bf16 F.linear for one layer's dense
+    weights; extrapolated to the full model.  A reported baseline, not a target."""
+    import oracle
+    cache, cfg = model.kv_cache, model.cfg
+    kv, G, D, C, S = cache.num_key_value_heads, cache.num_key_value_groups, cache.head_dim, cache.chunk_size, cache.select_sets
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    path_s = 0.0
+    for l in range(sample_layers):
+        lm = cache.k_landmark[l][0].cpu().contiguous(); lm_idx = cache.k_landmark_idx[l][0].cpu().contiguous()
+        N = lm.shape[1]; T = (N + 255) // 256
+        U = cache.U[l].cpu().contiguous(); SV = cache.SV[l].cpu().contiguous()
+        pos = cache.position_ids[l][0].cpu().clone()
+        kbuf = cache.k_cache_buffer[l].cpu().clone(); vbuf = cache.v_cache_buffer[l].cpu().clone()
+        vhost = cache.v_cache_cpu[l][0]
+        rows = kbuf.shape[2]
+        cs = model.cos_sin_cache.cpu()
+        qs = []
+        for _ in range(sample_steps):
+            walk.advance()
+            qs.append(walk.qb[l].cpu().view(kv, G, D).contiguous())
+        Dm = torch.zeros(kv, G, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
+        nm = torch.zeros(kv, T, G); sm = torch.zeros(kv, T, G)
+        off = torch.zeros(kv, S, dtype=torch.int32); cnt = torch.zeros(kv, dtype=torch.int32)
+        pre = torch.zeros(1, kv, S * C, D, dtype=torch.bfloat16)
+        t0 = time.perf_counter()
+        for q in qs:
+            oracle.batch_gemm_softmax(q, lm, Dm, nm, sm, P, kv, G, N, D, 1.0 / math.sqrt(128))
+            sel = oracle.group_max_topk(P, lm_idx, kv, G, N, S)
+            oracle.reorder_keys_and_compute_offsets(pos, sel, off, cnt, 1, kv, S)
+            oracle.gather_copy_with_offsets(vhost, vbuf[0], None, off, cnt, None, 1, kv, vhost.stride(0), S * C * D,
+                                            cache.sparse_start * D, rows * D, S)
+            oracle.gather_copy_d2d_with_offsets(kbuf[0], off, cnt, 1, kv, S * C * D, cache.sparse_start * D, rows * D, S)
+            ids32 = pos.to(torch.int32).view(1, kv, S).contiguous()
+            oracle.batch_gather_gemm(U, SV, None, None, ids32, pre, 1, kv, U.shape[1], D, cache.rank, S * C, 0, C, cnt)
+            ints = (1, kv, S * C, D, pre.stride(0), pre.stride(1), pre.stride(2), 1, cs.stride(0), ids32.stride(0),
+                    ids32.stride(1), ids32.stride(2), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
+                    cache.sparse_start, cache.sparse_end, 64, C)
+            (oracle.apply_rotary_pos_emb_push_cache_opt_glm if cfg.rope_style == "glm"
+             else oracle.apply_rotary_pos_emb_push_cache_opt)(pre, cs, ids32, kbuf, cnt, *ints)
+            oracle.sparse_attention(q.view(1, kv * G, D), kbuf, vbuf, cache.sparse_end + 1, 1.0 / math.sqrt(D))
+        path_s += time.perf_counter() - t0
+    path_ms_layer = path_s / (sample_layers * sample_steps) * 1e3
+    # dense layers on the CPU: one layer's weights, bf16 F.linear
+    lay = model.layers[0]
+    w = [lay.wqkv.cpu(), lay.wo.cpu(), lay.gate_up_proj.cpu(), lay.down_proj.cpu()]
+    x = torch.randn(1, 1, cfg.hidden_size).bfloat16(); xi = torch.randn(1, 1, cfg.intermediate_size).bfloat16()
+    for _ in range(2):
+        t0 = time.perf_counter()
+        torch.nn.functional.linear(x, w[0]); torch.nn.functional.linear(x, w[1])
+        torch.nn.functional.linear(x, w[2]); torch.nn.functional.linear(xi, w[3])
+        dense_ms_layer = (time.perf_counter() - t0) * 1e3
+    head_ms = dense_ms_layer * (cfg.vocab_size * cfg.hidden_size) / sum(t.numel() for t in w)
+    ms_token = (path_ms_layer + dense_ms_layer) * cfg.num_hidden_layers + head_ms
+    return dict(value=round(1e3 / ms_token, 4), unit="tokens/s", cores=cores, kind="port",
+                sample=(f"oracle (C/OpenMP) ShadowKV path of {sample_layers} layers x {sample_steps} tokens "
+                        f"({path_ms_layer:.1f} ms/layer) + torch-CPU bf16 dense of 1 layer ({dense_ms_layer:.1f} ms), "
+                        f"extrapolated to {cfg.num_hidden_layers} layers + lm_head"),
+                path_ms_per_layer=round(path_ms_layer, 2), dense_ms_per_layer=round(dense_ms_layer, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="llama31_122k", choices=list(WORKLOADS))
+    ap.add_argument("--layers", type=int, default=None, help="debug: fewer layers (result then marked invalid)")
+    ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
+    ap.add_argument("--walk-step", type=float, default=0.3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    numa = pin_to_gpu_numa_node(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from shadowkv_amd import llama
+    cfg_name, ctx, budget = WORKLOADS[args.workload]
+    cfg = getattr(llama, cfg_name)
+    t_build = time.perf_counter()
+    model = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
+                            chunk_size=8, num_layers=args.layers, seed=1234 + rank)
+    llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
+    walk = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
+    if args.query_mode == "walk":
+        model.query_hook = walk
+    cache = model.kv_cache
+    slack = cache.k_cache_buffer.shape[-2] - cache.sparse_end
+    t_build = time.perf_counter() - t_build
+
+    next_token = torch.randint(0, cfg.vocab_size, (1, 1), device=dev)
+    tokens = []
+
+    def step():
+        nonlocal next_token
+        if cache.gen_offset >= slack:                 # generated-token slack (96 rows at 122K) exhausted: the
+            cache.gen_offset = 0                      # reference silently drops further rows; rewind the
+            cache.kv_offset = ctx                     # bookkeeping instead so every step does full work
+        if args.query_mode == "walk":
+            walk.advance()
+        next_token = model.decode_step(next_token, temperature=0.6)
+        tokens.append(next_token[:, -1].tolist())     # per-step host sync, as base.py:635
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t)
+    else:
+        elapsed_max = elapsed
+    value = aggregate_throughput([args.steps] * world, [elapsed_max])
+    ms_per_step = elapsed_max / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        from shadowkv_amd import _lib
+        assert _lib.lib().skv_move_timeout_flag() == 0, "row mover spin timed out: results invalid"
+        roof = measure_score_kernel(model)
+        extras = {}
+        if not args.no_extras:
+            path_ms, hit_rate = measure_path_only(model, walk)
+            wbytes = model.weight_bytes()
+            B, N = cache.block_num, cache.k_landmark.shape[-2]
+            miss = 1.0 - hit_rate
+            path_bytes = model.num_layers * (B * N * 256 + B * cache.select_sets * 8
+                                              + miss * B * budget * (cache.rank * 2 + 2 * 256) + B * 128 * cache.rank * 2
+                                              + 2 * B * cache.sparse_end * 256)
+            extras = dict(path_ms_per_step=round(path_ms, 3), chunk_hit_rate=round(hit_rate, 4),
+                          weight_bytes=wbytes, path_algorithmic_bytes=int(path_bytes),
+                          step_hbm_frac_of_peak=round((wbytes + path_bytes) / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                          path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                          pcie_gbs_in_path=round(miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9, 2),
+                          state_build_s=round(t_build, 1), numa_node=numa, query_mode=args.query_mode,
+                          walk_step=args.walk_step)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "decode tokens/sec @122K ctx, Llama-3.1-8B, budget=2048 rank=160; 1/2/4/8 GPU"
+            if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}",
+            "value": round(value, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
+                                   f"chunk_size 8, bs 1 per GPU, {model.num_layers} layers"
+                                   + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)"),
+                       "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
+            "roofline": {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
+                         "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]},
+        }
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, walk)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

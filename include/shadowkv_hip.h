@@ -155,6 +155,12 @@ SKV_EXPORT int skv_select_chunks(const void* q, const void* landmarks, const int
                       int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
                       int blocks, int groups, int n_landmarks, int select_sets, float alpha, skv_stream_t stream);
 
+/* Stage 1 of skv_select_chunks alone (the HBM-bound landmark scan), for roofline measurement and
+ * profiling: logits bf16 [blocks][groups][n] and per-256-landmark partial (max, sum) f32
+ * [blocks][ceil(n/256)][groups].  Same kernel, same launch shape as inside skv_select_chunks. */
+SKV_EXPORT int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
+                        int blocks, int groups, int n_landmarks, float alpha, skv_stream_t stream);
+
 /* ShadowKVCache_CPU.get_value_cache (kv_cache.py:1059-1106): compaction of hit chunks + fetch of miss
  * chunks from the pinned host table into the sparse region.  Strides / offsets in bf16 elements.
  * host_values == NULL: compaction only (this is also the K-side compaction of get_key_cache,

@@ -235,6 +235,13 @@ int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landm
                                           selected_out, blocks, n_landmarks, select_sets, st));
 }
 
+int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
+                        int blocks, int groups, int n_landmarks, float alpha, skv_stream_t stream) {
+    if (!q || !landmarks || !logits || !part_max || !part_sum || blocks < 1 || n_landmarks < 1) return SKV_ERR_ARG;
+    return finish(skv_launch_score(q, landmarks, logits, part_max, part_sum, blocks, groups, n_landmarks, alpha,
+                                   (hipStream_t)stream));
+}
+
 int skv_move_chunks(const void* host_values, void* cache_buffer, const int32_t* offsets, const int32_t* cnts,
                     uint32_t* signals, long long host_block_stride, long long cache_block_stride,
                     long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream) {

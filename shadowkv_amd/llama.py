@@ -1,0 +1,275 @@
+"""Host-side decoder model for the ShadowKV decode path on MI355X.
+
+Mirrors the call structure of the reference's `LLM` / `Llama` / `GLM`
+(/root/reference/models/base.py:128-160 `inference`, :247-370 `layer_compute`;
+/root/reference/models/llama.py:283-427; /root/reference/models/glm.py) for the DECODE branch:
+pre_attention_compute -> apply_rotary_pos_emb -> kv_cache.update_kv_cache ->
+kv_cache.get_retrieval_position_ids -> [copy_stream: get_value_cache] || get_key_cache -> attention ->
+post_attention_compute.  Dense layers run on PyTorch-ROCm (`F.linear`, `F.rms_norm`); everything the
+reference gets from flash-attn / vLLM / flashinfer comes from shadowkv_amd.tensor_op.
+
+Weights: there are no checkpoints offline, so layers are created with random bf16 weights in the
+named architecture's shapes (`random_init=True`); `load_state(...)` accepts real tensors with the same
+fused layouts (wqkv = [q;k;v], gate_up = [gate;up]) as llama.py:111-128.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from . import tensor_op
+from .kv_cache import ShadowKVCache_CPU
+
+
+@dataclass
+class ModelConfig:
+    name: str = "llama-3.1-8b"
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    qkv_bias: bool = False
+    rope_style: str = "neox"          # "neox": half-split over 128 dims; "glm": interleaved pairs over the first 64 dims
+
+
+LLAMA_3_1_8B = ModelConfig()
+LLAMA_3_8B_1048K = ModelConfig(name="llama-3-8b-gradient-1048k", rope_theta=3580165449.0)
+GLM_4_9B_1M = ModelConfig(name="glm-4-9b-1m", intermediate_size=13696, num_hidden_layers=40, num_key_value_heads=4,
+                          vocab_size=151552, rms_norm_eps=1.5625e-07, rope_theta=10000.0 * 1e4, qkv_bias=True,
+                          rope_style="glm")
+
+
+class DecoderLayer:
+    """Fused weight layout of the reference's LlamaLayer (llama.py:59-152)."""
+
+    def __init__(self, cfg, device, dtype, gen):
+        h, i = cfg.hidden_size, cfg.intermediate_size
+        d = h // cfg.num_attention_heads
+        self.q_size, self.kv_size = h, cfg.num_key_value_heads * d
+
+        def w(*shape):
+            return (torch.randn(*shape, device=device, dtype=torch.float32, generator=gen) * 0.02).to(dtype)
+
+        self.wqkv = w(self.q_size + 2 * self.kv_size, h)
+        self.bqkv = w(self.q_size + 2 * self.kv_size) if cfg.qkv_bias else None
+        self.wo = w(h, h)
+        self.gate_up_proj = w(2 * i, h)
+        self.down_proj = w(h, i)
+        self.input_layernorm_weight = torch.ones(h, device=device, dtype=dtype)
+        self.post_attention_layernorm_weight = torch.ones(h, device=device, dtype=dtype)
+        self.input_layernorm_variance_epsilon = cfg.rms_norm_eps
+        self.post_attention_layernorm_variance_epsilon = cfg.rms_norm_eps
+
+
+def build_cos_sin_cache(cfg, max_pos, device, dtype):
+    """[max_pos, 128] = cos[:64] | sin[:64] (llama.py:323-332) or, GLM, [max_pos, 64] = cos[:32] | sin[:32]
+    (glm.py:261-273)."""
+    rot = cfg.hidden_size // cfg.num_attention_heads if cfg.rope_style == "neox" else 64
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, rot, 2, dtype=torch.float32, device=device) / rot))
+    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32, device=device), inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype).contiguous()
+
+
+class DecoderLM:
+    def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
+                 attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
+                 num_layers=None):
+        if attn_mode != "shadowkv_cpu":
+            raise ValueError("this build covers the ShadowKV offload decode path (attn_mode='shadowkv_cpu')")
+        self.cfg = cfg
+        self.config = cfg
+        self.batch_size, self.max_length = batch_size, max_length
+        self.device, self.dtype = torch.device(device), dtype
+        self.hidden_size = cfg.hidden_size
+        self.num_heads = cfg.num_attention_heads
+        self.num_key_value_heads = cfg.num_key_value_heads
+        self.head_dim = cfg.hidden_size // cfg.num_attention_heads
+        self.num_layers = num_layers or cfg.num_hidden_layers
+        self.vocab_size = cfg.vocab_size
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        if not random_init:
+            raise NotImplementedError("no checkpoints are available offline; use random_init=True or load_state()")
+        self.embed_tokens = (torch.randn(cfg.vocab_size, cfg.hidden_size, device=self.device, dtype=torch.float32,
+                                         generator=gen) * 0.02).to(dtype)
+        self.lm_head = (torch.randn(cfg.vocab_size, cfg.hidden_size, device=self.device, dtype=torch.float32,
+                                    generator=gen) * 0.02).to(dtype)
+        self.norm_weight = torch.ones(cfg.hidden_size, device=self.device, dtype=dtype)
+        self.norm_variance_epsilon = cfg.rms_norm_eps
+        self.layers = [DecoderLayer(cfg, self.device, dtype, gen) for _ in range(self.num_layers)]
+        self.cos_sin_cache = build_cos_sin_cache(cfg, max_length + 1024, self.device, dtype)
+
+        class _CacheCfg:
+            num_hidden_layers = self.num_layers
+            num_attention_heads = cfg.num_attention_heads
+            num_key_value_heads = cfg.num_key_value_heads
+            hidden_size = cfg.hidden_size
+
+        self.kv_cache = ShadowKVCache_CPU(_CacheCfg, batch_size=batch_size, max_length=max_length, device=device,
+                                          dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size, rank=rank)
+        self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
+
+    def weight_bytes(self):
+        n = self.lm_head.numel()   # one embedding row is read per token: not counted
+        for l in self.layers:
+            n += l.wqkv.numel() + l.wo.numel() + l.gate_up_proj.numel() + l.down_proj.numel()
+        return n * 2
+
+    # --------------------------------------------------------------- per-layer pieces (llama.py:283-427)
+    def pre_attention_compute(self, hidden_states, layer):
+        hs = tensor_op.layer_norm(hidden_states, layer.input_layernorm_variance_epsilon, layer.input_layernorm_weight)
+        qkv = F.linear(hs, layer.wqkv, layer.bqkv)
+        q, k, v = qkv.split([layer.q_size, layer.kv_size, layer.kv_size], dim=-1)
+        return q, k, v.view(v.shape[0], -1, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+
+    def apply_rotary_pos_emb(self, q, k, position_ids):
+        """q [bs, s, Hq*D], k [bs, s, Hkv*D] -> [bs, H, s, D] rotated at position_ids [bs, s]."""
+        bs, s = q.shape[0], q.shape[1]
+        q = q.view(bs, s, self.num_heads, self.head_dim).transpose(1, 2)
+        k = k.view(bs, s, self.num_key_value_heads, self.head_dim).transpose(1, 2)
+        if self.cfg.rope_style == "neox":
+            pid_q = position_ids.unsqueeze(1).expand(-1, self.num_heads, -1).contiguous()
+            pid_k = position_ids.unsqueeze(1).expand(-1, self.num_key_value_heads, -1).contiguous()
+            return (tensor_op.apply_rotary_pos_emb_cuda(q.contiguous(), self.cos_sin_cache, pid_q),
+                    tensor_op.apply_rotary_pos_emb_cuda(k.contiguous(), self.cos_sin_cache, pid_k))
+        return self._rope_glm(q, position_ids), self._rope_glm(k, position_ids)
+
+    def _rope_glm(self, x, position_ids):
+        cs = self.cos_sin_cache[position_ids].unsqueeze(1)          # [bs, 1, s, 64]
+        c, s = cs[..., :32], cs[..., 32:]
+        xr, xp = x[..., :64], x[..., 64:]
+        xe, xo = xr[..., 0::2], xr[..., 1::2]
+        out = torch.stack((xe * c - xo * s, xo * c + xe * s), dim=-1).flatten(-2)
+        return torch.cat((out, xp), dim=-1).contiguous()
+
+    def post_attention_compute(self, attn_output, residual, layer):
+        hs = residual + F.linear(attn_output, layer.wo)
+        residual = hs
+        hs = tensor_op.layer_norm(hs, layer.post_attention_layernorm_variance_epsilon,
+                                  layer.post_attention_layernorm_weight)
+        hs = F.linear(hs, layer.gate_up_proj)
+        d = hs.shape[-1] // 2
+        act = torch.empty(hs.shape[:-1] + (d,), dtype=hs.dtype, device=hs.device)
+        tensor_op.silu_and_mul(act, hs)
+        return residual + F.linear(act, layer.down_proj)
+
+    # --------------------------------------------------------------- decode branch of layer_compute (base.py:315-341)
+    @torch.inference_mode()
+    def layer_compute(self, layer, layer_idx, hidden_states, position_ids):
+        residual = hidden_states
+        bsz, q_len, _ = hidden_states.shape
+        q, k, v = self.pre_attention_compute(hidden_states, layer)
+        q, k = self.apply_rotary_pos_emb(q, k, position_ids)
+        if self.query_hook is not None:
+            q = self.query_hook(layer_idx, q)
+        cache = self.kv_cache
+        cache.update_kv_cache(k, v, layer_idx)
+        chunk_ids = cache.get_retrieval_position_ids(layer_idx=layer_idx, query_states=q)
+        curr = torch.cuda.current_stream()
+        side = cache.copy_stream
+        with torch.cuda.stream(side):
+            side.wait_stream(curr)
+            v_view = cache.get_value_cache(layer_idx, chunk_ids)
+        k_view = cache.get_key_cache(layer_idx=layer_idx, position_ids=chunk_ids, rope_func=None,
+                                     cos_sin_cache=self.cos_sin_cache)
+        curr.wait_stream(side)
+        attn = tensor_op.sparse_attention_decode(q, k_view, v_view)
+        return self.post_attention_compute(attn.reshape(bsz, q_len, self.hidden_size), residual, layer)
+
+    def get_ctx(self, input_ids):
+        past = self.kv_cache.get_kv_len()
+        n = input_ids.size(1)
+        return torch.arange(past, past + n, device=self.device, dtype=torch.long).unsqueeze(0).repeat(input_ids.size(0), 1)
+
+    @torch.inference_mode()
+    def inference(self, input_ids, position_ids):
+        hs = F.embedding(input_ids, self.embed_tokens)
+        for idx in range(self.num_layers):
+            hs = self.layer_compute(self.layers[idx], idx, hs, position_ids)
+        hs = tensor_op.layer_norm(hs, self.norm_variance_epsilon, self.norm_weight)
+        return F.linear(hs, self.lm_head).float()
+
+    @torch.inference_mode()
+    def decode_step(self, next_token, temperature=0.6, top_p=0.9, top_k=50):
+        """One iteration of the reference's timed loop (base.py:628-635)."""
+        logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
+        return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k)
+
+
+class Llama(DecoderLM):
+    pass
+
+
+class GLM(DecoderLM):
+    def __init__(self, cfg=GLM_4_9B_1M, **kw):
+        super().__init__(cfg=cfg, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic long-context state (no 122K-token prefill offline): SURVEY.md section 8d
+# ------------------------------------------------------------------------------------------------
+@torch.inference_mode()
+def build_synthetic_context(model, context_len, seed=1234, q_scale=0.25):
+    """Fills the model's ShadowKVCache_CPU as a `context_len`-token prefill would, from synthetic
+    tensors: per layer U ~ N(0,1) [L, r], SV ~ N(0, 1/r) [kv, D, r] (so the pre-RoPE keys K = U.SV^T are
+    exactly rank r, unit variance), V ~ N(0,1); keys are rotated and handed with V to the cache's own
+    prefill_kv_cache (landmarks, outliers, local rows, host V table, initial selection).  Returns the
+    last-token query used for the initial selection."""
+    cache, cfg = model.kv_cache, model.cfg
+    dev, dt = model.device, model.dtype
+    kv, D, r, L = cfg.num_key_value_heads, model.head_dim, cache.rank, context_len
+    bs = model.batch_size
+    pos = torch.arange(L, device=dev).unsqueeze(0).expand(bs, -1)
+    cache.U = torch.zeros(model.num_layers, bs, L, r, device=dev, dtype=dt)
+    cache.SV = torch.zeros(model.num_layers, bs, kv, D, r, device=dev, dtype=dt)
+    q_last = None
+    for l in range(model.num_layers):
+        g = torch.Generator(device=dev).manual_seed(seed + l)
+        U = torch.randn(bs, L, r, device=dev, generator=g).to(dt)
+        SV = (torch.randn(bs, kv, D, r, device=dev, generator=g) / math.sqrt(r)).to(dt)
+        cache.U[l].copy_(U)
+        cache.SV[l].copy_(SV)
+        k_pre = torch.einsum("blr,bhdr->bhld", U.float(), SV.float()).to(dt)            # [bs, kv, L, D]
+        if cfg.rope_style == "neox":
+            pid = pos.unsqueeze(1).expand(-1, kv, -1).contiguous()
+            k_roped = tensor_op.apply_rotary_pos_emb_cuda(k_pre.contiguous(), model.cos_sin_cache, pid)
+        else:
+            k_roped = model._rope_glm(k_pre, pos)
+        v = torch.randn(bs, kv, L, D, device=dev, generator=g).to(dt)
+        q_last = torch.randn(bs, cfg.num_attention_heads, 1, D, device=dev, generator=g)
+        q_last = (q_last / q_last.norm(dim=-1, keepdim=True) * math.sqrt(D) * q_scale * 4).to(dt)
+        cache.prefill_kv_cache(v, l, k_roped, q_last)
+        del U, SV, k_pre, k_roped, v
+    cache.H2D()
+    torch.cuda.synchronize(dev)
+    return q_last
+
+
+class QueryWalk:
+    """Synthetic per-layer query trajectory: q_t = normalize(q_{t-1} + step*N(0,1)) * |q|,
+    so consecutive selections overlap like a real model's; `step` tunes the chunk hit rate.  Used as
+    DecoderLM.query_hook: the walk REPLACES the values of the model's post-RoPE query while keeping its
+    data dependency (q_model * 0 + q_walk), because random-init weights carry no attention locality."""
+
+    def __init__(self, model, step=0.3, q_scale=0.25, seed=99):
+        dev = model.device
+        self.g = torch.Generator(device=dev).manual_seed(seed)
+        D = model.head_dim
+        self.norm = math.sqrt(D) * q_scale * 4
+        self.step = step
+        self.q = torch.randn(model.num_layers, model.batch_size, model.num_heads, 1, D, device=dev, generator=self.g)
+        self.q = self.q / self.q.norm(dim=-1, keepdim=True) * self.norm
+        self.qb = self.q.to(model.dtype)
+
+    def advance(self):
+        n = torch.randn(self.q.shape, device=self.q.device, generator=self.g)
+        self.q = self.q + self.step * self.norm / math.sqrt(self.q.shape[-1]) * n
+        self.q = self.q / self.q.norm(dim=-1, keepdim=True) * self.norm
+        self.qb = self.q.to(self.qb.dtype)
+
+    def __call__(self, layer_idx, q_model):
+        return torch.addcmul(self.qb[layer_idx], q_model, torch.zeros((), device=q_model.device, dtype=q_model.dtype))
