@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="llama31_122k", choices=list(WORKLOADS))
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer layers (result then marked invalid)")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph: the decode step is captured once into a hipGraph and replayed (default); "
+                         "eager: every launch issued from Python each step")
     ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
     ap.add_argument("--walk-step", type=float, default=0.3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -227,23 +230,40 @@ def main():
                             chunk_size=8, num_layers=args.layers, seed=1234 + rank)
     llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
     walk = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
-    if args.query_mode == "walk":
-        model.query_hook = walk
     cache = model.kv_cache
     slack = cache.k_cache_buffer.shape[-2] - cache.sparse_end
     t_build = time.perf_counter() - t_build
 
     next_token = torch.randint(0, cfg.vocab_size, (1, 1), device=dev)
     tokens = []
+    mode = args.mode
+    dec = None
+    if mode == "graph":
+        table = None
+        if args.query_mode == "walk":
+            table = llama.make_walk_table(model, args.warmup + args.steps + 4, step=args.walk_step, seed=99 + rank)
+        dec = llama.GraphDecoder(model, temperature=0.6, walk_table=table)
+        dec.token.copy_(next_token)
+        try:
+            dec.capture()
+        except Exception as e:                              # keep the run alive, say so in the output
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+            mode = "eager"
+            dec = None
+    if mode == "eager" and args.query_mode == "walk":
+        model.query_hook = walk
 
     def step():
         nonlocal next_token
-        if cache.gen_offset >= slack:                 # generated-token slack (96 rows at 122K) exhausted: the
-            cache.gen_offset = 0                      # reference silently drops further rows; rewind the
-            cache.kv_offset = ctx                     # bookkeeping instead so every step does full work
-        if args.query_mode == "walk":
-            walk.advance()
-        next_token = model.decode_step(next_token, temperature=0.6)
+        if dec is not None:
+            next_token = dec.step()
+        else:
+            if cache.gen_offset >= slack:             # generated-token slack (96 rows at 122K) exhausted: the
+                cache.gen_offset = 0                  # reference silently drops further rows; rewind the
+                cache.kv_offset = ctx                 # bookkeeping instead so every step does full work
+            if args.query_mode == "walk":
+                walk.advance()
+            next_token = model.decode_step(next_token, temperature=0.6)
         tokens.append(next_token[:, -1].tolist())     # per-step host sync, as base.py:635
 
     for _ in range(args.warmup):
@@ -288,7 +308,7 @@ def main():
                           step_hbm_frac_of_peak=round((wbytes + path_bytes) / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                           path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                           pcie_gbs_in_path=round(miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9, 2),
-                          state_build_s=round(t_build, 1), numa_node=numa, query_mode=args.query_mode,
+                          state_build_s=round(t_build, 1), numa_node=numa, query_mode=args.query_mode, launch_mode=mode,
                           walk_step=args.walk_step)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")

@@ -11,10 +11,11 @@ int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float*
                      float alpha, hipStream_t st);
 int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void* P, int B, int m, int N,
                                    hipStream_t st);
-int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score, int B,
-                                  int G, int N, hipStream_t st);
-int skv_launch_topk_reorder(const void* score, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
-                            int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S, hipStream_t st);
+int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
+                                  int score_stride, int B, int G, int N, hipStream_t st);
+int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
+                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
+                            hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, const int32_t* offsets, const int32_t* cnts,
                          unsigned int* signals, long long host_len_elems, long long dev_stride_elems,
                          long long dev_off_elems, int B, int S, hipStream_t st);
@@ -56,6 +57,7 @@ struct SelectWs {
     float* pmax;
     float* psum;
     void* score;
+    int score_stride;
     size_t total;
 };
 static SelectWs carve_select_ws(void* base, int blocks, int groups, int n) {
@@ -70,7 +72,8 @@ static SelectWs carve_select_ws(void* base, int blocks, int groups, int n) {
     w.psum = (float*)(p + off);
     off += align256((size_t)blocks * T * groups * 4);
     w.score = p + off;
-    off += align256((size_t)blocks * n * 2);
+    w.score_stride = (n + 7) & ~7;  // rows start 16-B aligned for the vector staging loads
+    off += align256((size_t)blocks * w.score_stride * 2);
     w.total = off;
     return w;
 }
@@ -96,7 +99,7 @@ int skv_reorder_keys_and_compute_offsets(int64_t* cached_pos_ids, const int64_t*
                                          int32_t* cnts, int batch_size, int heads, int map_size,
                                          skv_stream_t stream) {
     if (!cached_pos_ids || !cur_pos_ids || !offsets || !cnts || batch_size * heads < 1) return SKV_ERR_ARG;
-    return finish(skv_launch_topk_reorder(nullptr, nullptr, cur_pos_ids, cached_pos_ids, offsets, cnts, nullptr,
+    return finish(skv_launch_topk_reorder(nullptr, 0, nullptr, cur_pos_ids, cached_pos_ids, offsets, cnts, nullptr,
                                           batch_size * heads, 0, map_size, (hipStream_t)stream));
 }
 
@@ -229,9 +232,10 @@ int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landm
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st);
     if (rc != SKV_OK) return rc;
-    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, blocks, groups, n_landmarks, st);
+    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
+                                       n_landmarks, st);
     if (rc != SKV_OK) return rc;
-    return finish(skv_launch_topk_reorder(w.score, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
+    return finish(skv_launch_topk_reorder(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
                                           selected_out, blocks, n_landmarks, select_sets, st));
 }
 

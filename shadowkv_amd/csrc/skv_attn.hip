@@ -17,13 +17,14 @@
 
 #define AT_D 128
 #define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
+#define AT_REC 132     // floats per (head, split) record: acc[128], m, l, 2 pad (16-B aligned rows)
 
 template <int G>
 __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     const bf16_t* __restrict__ q,   // [bs][Hq][128]
     const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
     const bf16_t* __restrict__ v,
-    float* __restrict__ ws,         // [bs*Hkv][splits][G][130]  (m, l, acc[128])
+    float* __restrict__ ws,         // [bs*Hkv][G][splits][AT_REC]  (acc[128], m, l)
     const int* __restrict__ kv_len_dev, int kv_len_host, long long kv_stride_h /*elements*/, int Hkv, int splits,
     float scale) {
     const int bh = blockIdx.y, split = blockIdx.x;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
             a = __builtin_fmaf(s_part[r][g][d], w, a);
             L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
         }
-        float* dst = ws + (((size_t)bh * splits + split) * G + g) * (AT_D + 2);
+        float* dst = ws + (((size_t)bh * G + g) * splits + split) * AT_REC;
         dst[d] = a;
         if (d == 0) {
             dst[AT_D] = M;
@@ -115,15 +116,26 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
 }
 
 __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
-                                                               int G, int splits) {
-    // block = one query head (b, hq); thread = output dim
+                                                               int splits) {
+    // block = one query head; its `splits` records are contiguous (splits*528 B): pulled into LDS with
+    // 16-B loads that are all in flight together (one memory round trip), then merged from LDS.
+    extern __shared__ __attribute__((aligned(16))) float s_rec[];  // [splits][AT_REC]
     const int bq = blockIdx.x, d = threadIdx.x;
-    const int bh = bq / G, g = bq % G;
+    const u32x4* src = reinterpret_cast<const u32x4*>(ws + (size_t)bq * splits * AT_REC);
+    const int nvec = splits * (AT_REC / 4);
+    u32x4 tmp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (d + k * 128 < nvec) tmp[k] = src[d + k * 128];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (d + k * 128 < nvec) reinterpret_cast<u32x4*>(s_rec)[d + k * 128] = tmp[k];
+    __syncthreads();
     float M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, ws[(((size_t)bh * splits + s) * G + g) * (AT_D + 2) + AT_D]);
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, s_rec[s * AT_REC + AT_D]);
     float a = 0.f, L = 0.f;
     for (int s = 0; s < splits; ++s) {
-        const float* p = ws + (((size_t)bh * splits + s) * G + g) * (AT_D + 2);
+        const float* p = s_rec + s * AT_REC;
         float w = (p[AT_D] == -INFINITY) ? 0.f : __expf(p[AT_D] - M);
         a = __builtin_fmaf(p[d], w, a);
         L = __builtin_fmaf(p[AT_D + 1], w, L);
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __re
     out[(size_t)bq * AT_D + d] = f2bf(a / L);
 }
 
-extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return (size_t)bs * Hq * splits * (AT_D + 2) * sizeof(float); }
+extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return (size_t)bs * Hq * splits * AT_REC * sizeof(float); }
 
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
                                 const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
@@ -160,7 +172,8 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         default: return SKV_ERR_UNSUPPORTED;
     }
 #undef SKV_AT
-    hipLaunchKernelGGL(skv_attn_combine_kernel, dim3(bs * Hq), dim3(128), 0, st, (const float*)ws, (bf16_t*)out, G,
-                       splits);
+    if (splits > 62) return SKV_ERR_UNSUPPORTED;   // 16 x 128 staging vectors per block
+    hipLaunchKernelGGL(skv_attn_combine_kernel, dim3(bs * Hq), dim3(128), (size_t)splits * AT_REC * sizeof(float), st,
+                       (const float*)ws, (bf16_t*)out, splits);
     return SKV_OK;
 }

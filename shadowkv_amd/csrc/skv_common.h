@@ -18,13 +18,9 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even, NaN stays NaN (same as oracle f2bf / v_cvt_pk_bf16_f32)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN: one v_cvt_pk_bf16_f32 (same results as the oracle's f2bf
+// for every non-NaN input)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
@@ -70,20 +66,95 @@ __device__ __forceinline__ float fixed_to_float(unsigned long long S) {
 }
 
 // ---- cross-lane helpers (wave64) ------------------------------------------------------
+// DPP row operations (no LDS traffic, unlike __shfl_xor which lowers to ds_bpermute_b32).
+// 0xB1 = quad_perm[1,0,3,2] (lane^1), 0x4E = quad_perm[2,3,0,1] (lane^2),
+// 0x141 = row_half_mirror (lane i <-> 7-i inside 8 lanes), 0x140 = row_mirror (i <-> 15-i).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 // sum over the 16 lanes of a DPP row as the balanced tree ((p0+p1)+(p2+p3))+... ; every
-// lane of the row ends with the same value (IEEE add is commutative).
+// lane of the row ends with the same value (IEEE add is commutative, and after the first two
+// steps all lanes of a quad hold the quad sum, so the mirrors deliver "the other half's" sum).
 __device__ __forceinline__ float row16_tree_sum(float v) {
-    v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    v = v + __shfl_xor(v, 4, 64);
-    v = v + __shfl_xor(v, 8, 64);
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
     return v;
 }
+// lane i <-> lane i^4 inside a row: two bank-masked row shifts (banks = quads of the row)
+__device__ __forceinline__ float dpp_xor4(float v) {
+    int x = __float_as_int(v);
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x104 /*row_shl:4*/, 0xF, 0x5, false);   // quads 0,2 <- lane+4
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114 /*row_shr:4*/, 0xF, 0xA, false);       // quads 1,3 <- lane-4
+    return __int_as_float(r);
+}
+// Reduce NV values per lane over the 16 lanes of a row with the SAME tree as row16_tree_sum
+// (xor 1, 2, 4, 8), transposing as it goes: at each of the first log2(NV) stages a lane keeps half of
+// its values and hands the other half to its partner, so it finishes with ONE value, the row total
+// for index g = row16_owner<NV>(lane).  x[l] + x[l^m] is computed by both partners (commutative), so
+// every lane that ends up with the same g holds the same bits.
+// per-lane select by a constant 64-bit lane mask: one v_cndmask_b32, no compare (hipcc otherwise
+// re-materialises a v_cmp on the lane id for every select)
+__device__ __forceinline__ float sel_lanes(float if_clear, float if_set, unsigned long long lane_mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+    return r;
+}
+template <int NV>
+__device__ __forceinline__ float row16_tree_sum_transposed(float (&v)[NV], int lane) {
+    (void)lane;
+    int nv = NV;
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+        // lanes whose index bit `stage` is set
+        const unsigned long long bitmask = stage == 0   ? 0xAAAAAAAAAAAAAAAAull
+                                           : stage == 1 ? 0xCCCCCCCCCCCCCCCCull
+                                           : stage == 2 ? 0xF0F0F0F0F0F0F0F0ull
+                                                        : 0xFF00FF00FF00FF00ull;
+        if (nv > 1) {
+            const int half = nv / 2;
+#pragma unroll
+            for (int k = 0; k < NV / 2; ++k) {
+                if (k < half) {
+                    const float keep = sel_lanes(v[k], v[k + half], bitmask);
+                    const float give = sel_lanes(v[k + half], v[k], bitmask);
+                    const float got = stage == 0 ? dpp_mov<0xB1>(give)
+                                      : stage == 1 ? dpp_mov<0x4E>(give)
+                                      : stage == 2 ? dpp_xor4(give) : dpp_mov<0x128>(give);
+                    v[k] = keep + got;
+                }
+            }
+            nv = half;
+        } else {
+            const float got = stage == 0 ? dpp_mov<0xB1>(v[0])
+                              : stage == 1 ? dpp_mov<0x4E>(v[0])
+                              : stage == 2 ? dpp_xor4(v[0]) : dpp_mov<0x128>(v[0]);
+            v[0] = v[0] + got;
+        }
+    }
+    return v[0];
+}
+// which of the NV values lane `lane` ends up owning, and whether it is the lane that should publish it
+template <int NV>
+__device__ __forceinline__ int row16_owner(int lane) {
+    int g = 0, w = NV / 2;
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+        if (w >= 1) g += ((lane >> stage) & 1) * w;
+        w /= 2;
+    }
+    return g;
+}
+template <int NV>
+__device__ __forceinline__ bool row16_publisher(int lane) {
+    // lanes whose non-transposed index bits are zero (one per g and row)
+    constexpr int stages = NV >= 16 ? 4 : NV >= 8 ? 3 : NV >= 4 ? 2 : NV >= 2 ? 1 : 0;
+    return ((lane & 15) >> stages) == 0;
+}
 __device__ __forceinline__ float wave_tree_sum(float v) {
-    v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    v = v + __shfl_xor(v, 4, 64);
-    v = v + __shfl_xor(v, 8, 64);
+    v = row16_tree_sum(v);
     v = v + __shfl_xor(v, 16, 64);
     v = v + __shfl_xor(v, 32, 64);
     return v;

@@ -65,11 +65,16 @@ __global__ __launch_bounds__(256) void skv_move_rows_kernel(
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(&signals[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Poll with backoff: a team waits for its slowest member (PCIe rows: tens of us), and every
+            // poll is an uncached access to one line that the arriving atomics also need - hundreds of
+            // workgroups polling every 0.1 us saturate that L2 channel and delay the arrivals themselves.
             unsigned spins = 0;
             while ((__hip_atomic_load(&signals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu) <
                    (unsigned)wgs_per_team) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 24)) {
+                if (spins < 4) __builtin_amdgcn_s_sleep(8);
+                else if (spins < 12) __builtin_amdgcn_s_sleep(24);
+                else __builtin_amdgcn_s_sleep(48);
+                if (++spins > (1u << 22)) {
                     atomicOr(&g_skv_move_timeout, 1u);
                     break;
                 }

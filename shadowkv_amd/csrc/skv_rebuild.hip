@@ -29,7 +29,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define RB_SV_PITCH 336  // bytes per SV row in LDS (320 + 16 pad)
 #define RB_OUT_PITCH 272 // bytes per output row in LDS (256 + 16 pad)
 
-template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/>
+__device__ __forceinline__ long long chunk_id_at(const void* ids, int ids64, size_t idx) {
+    return ids64 ? ((const int64_t*)ids)[idx] : (long long)((const int32_t*)ids)[idx];
+}
+
+// KS = rank / 32 k-steps (5 for rank 160); every loop below has a compile-time trip count so the
+// compiler batches the global loads of a phase instead of waiting on each one.
+template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/, int KS>
 __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const bf16_t* __restrict__ U,        // [bs][seq_len][R]
     const bf16_t* __restrict__ SV,       // [bs][heads][128][R]
@@ -37,8 +43,13 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const void* __restrict__ ids,        // [bs][heads][S] chunk id per slot (int64 or int32)
     const int32_t* __restrict__ cnts,    // [bs*heads] (nullable -> 0)
     bf16_t* __restrict__ out,            // MODE 0: [bs][heads][S*C][128]; else key cache
-    int heads, int seq_len, int R, int S, int C, int ids64, long long cs_stride,
+    int heads, int seq_len, int S, int C, int ids64, long long cs_stride,
     long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0) {
+    constexpr int R = KS * 32;
+    constexpr int UNITS_PER_ROW = R / 8;                       // 16-B units per SV row
+    constexpr int SV_ITERS = (RB_D * UNITS_PER_ROW + 255) / 256;
+    constexpr int EPI_UNITS = MODE == 1 ? 8 : 16;              // 8-element units per output row
+    constexpr int EPI_ITERS = RB_ROWS * EPI_UNITS / 256;       // 2 (Llama) or 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sSV = smem;                         // 128 x 336 B
     unsigned char* sOut = smem + RB_D * RB_SV_PITCH;   // 64 x 272 B
@@ -48,53 +59,77 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const int cnt = cnts ? cnts[bh] : 0;
     if (i0 + RB_ROWS <= cnt * C) return;  // every row of this tile is a resident (hit) row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ksteps = R / 32;
 
-    // ---- A fragments: issue the gathers first
+    // ---- phase 1: issue every global load this workgroup needs
+    // A fragments (gathered U rows)
     const int arow = i0 + wave * 16 + (lane & 15);
     long long pos = 0;
     if (arow < total_rows) {
-        long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + arow / C]
-                             : (long long)((const int32_t*)ids)[(size_t)bh * S + arow / C];
-        pos = id * C + arow % C;
+        pos = chunk_id_at(ids, ids64, (size_t)bh * S + arow / C) * C + arow % C;
         if (pos < 0 || pos >= seq_len) pos = 0;  // invalid ids are a caller error; never fault
     }
     const bf16_t* urow = U + ((size_t)b * seq_len + pos) * R + 8 * (lane >> 4);
-    u32x4 afrag[8];
+    u32x4 afrag[KS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        if (ks < ksteps) afrag[ks] = *reinterpret_cast<const u32x4*>(urow + 32 * ks);
-
-    // ---- stage SV[b][h] (128 rows x R) into LDS
+    for (int ks = 0; ks < KS; ++ks) afrag[ks] = *reinterpret_cast<const u32x4*>(urow + 32 * ks);
+    // SV[b][h] -> registers (stored to LDS below)
+    u32x4 svreg[SV_ITERS];
     {
-        const int units_per_row = R / 8;  // 16-B units
-        const int total_units = RB_D * units_per_row;
         const u32x4* src = reinterpret_cast<const u32x4*>(SV + (size_t)bh * RB_D * R);
-        for (int u = tid; u < total_units; u += 256) {
-            int row = u / units_per_row, c16 = u % units_per_row;
-            *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = src[u];
+#pragma unroll
+        for (int it = 0; it < SV_ITERS; ++it) {
+            const int u = tid + it * 256;
+            if (u < RB_D * UNITS_PER_ROW) svreg[it] = src[u];
+        }
+    }
+    // cos / sin of the rows this thread will finish in the epilogue
+    u32x4 ecos[MODE == 0 ? 1 : EPI_ITERS], esin[MODE == 0 ? 1 : EPI_ITERS];
+    bool evalid[EPI_ITERS];
+#pragma unroll
+    for (int it = 0; it < EPI_ITERS; ++it) {
+        const int u = tid + it * 256;
+        const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
+        evalid[it] = (i < total_rows) && (i >= cnt * C);
+        if (MODE != 0 && evalid[it]) {
+            const long long p = chunk_id_at(ids, ids64, (size_t)bh * S + i / C) * C + i % C;
+            const bf16_t* cs = cos_sin + p * cs_stride;
+            if (MODE == 1) {
+                ecos[it] = *reinterpret_cast<const u32x4*>(cs + 8 * c);
+                esin[it] = *reinterpret_cast<const u32x4*>(cs + 64 + 8 * c);
+            } else if (c < 8) {
+                u32x2 c2 = *reinterpret_cast<const u32x2*>(cs + 4 * c);
+                u32x2 s2 = *reinterpret_cast<const u32x2*>(cs + 32 + 4 * c);
+                ecos[it][0] = c2[0]; ecos[it][1] = c2[1];
+                esin[it][0] = s2[0]; esin[it][1] = s2[1];
+            }
+        }
+    }
+    // ---- phase 2: SV -> LDS (rows padded to 336 B: conflict-free 16-row x 16-B fragment reads)
+#pragma unroll
+    for (int it = 0; it < SV_ITERS; ++it) {
+        const int u = tid + it * 256;
+        if (u < RB_D * UNITS_PER_ROW) {
+            const int row = u / UNITS_PER_ROW, c16 = u % UNITS_PER_ROW;
+            *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = svreg[it];
         }
     }
     __syncthreads();
 
-    // ---- MFMA: acc[nb] covers rows wave*16.., columns nb*16..
+    // ---- phase 3: MFMA: acc[nb] covers rows wave*16.., columns nb*16..
     f32x4 acc[8];
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        if (ks < ksteps) {
-            bf16x8 a = __builtin_bit_cast(bf16x8, afrag[ks]);
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 a = __builtin_bit_cast(bf16x8, afrag[ks]);
 #pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                u32x4 braw = *reinterpret_cast<const u32x4*>(sSV + (nb * 16 + (lane & 15)) * RB_SV_PITCH + ks * 64 +
-                                                              (lane >> 4) * 16);
-                bf16x8 bb = __builtin_bit_cast(bf16x8, braw);
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nb], 0, 0, 0);
-            }
+        for (int nb = 0; nb < 8; ++nb) {
+            u32x4 braw = *reinterpret_cast<const u32x4*>(sSV + (nb * 16 + (lane & 15)) * RB_SV_PITCH + ks * 64 +
+                                                          (lane >> 4) * 16);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, braw), acc[nb], 0, 0, 0);
         }
     }
-    // ---- accumulators -> bf16 tile in LDS (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
+    // accumulators -> bf16 tile in LDS (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -104,71 +139,43 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
         }
     __syncthreads();
 
-    // ---- row-wise epilogue
-    if (MODE == 0) {
-        // 64 rows x 16 units of 16 B
-        for (int u = tid; u < RB_ROWS * 16; u += 256) {
-            int row = u >> 4, c16 = u & 15, i = i0 + row;
-            if (i >= total_rows || i < cnt * C) continue;
-            u32x4 v = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c16 * 16);
-            *reinterpret_cast<u32x4*>(out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
-                                      (size_t)(out_row0 + i) * out_stride_s + c16 * 8) = v;
-        }
-    } else if (MODE == 1) {
-        // NeoX half split: unit u (0..7) pairs elements [8u, 8u+8) with [64+8u, 64+8u+8)
-        for (int u = tid; u < RB_ROWS * 8; u += 256) {
-            int row = u >> 3, c = u & 7, i = i0 + row;
-            if (i >= total_rows || i < cnt * C) continue;
-            long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + i / C]
-                                 : (long long)((const int32_t*)ids)[(size_t)bh * S + i / C];
-            long long p = id * C + i % C;
-            const bf16_t* cs = cos_sin + p * cs_stride;
+    // ---- phase 4: row-wise epilogue (RoPE in bf16 arithmetic, 16-B stores, whole 256-B rows)
+#pragma unroll
+    for (int it = 0; it < EPI_ITERS; ++it) {
+        if (!evalid[it]) continue;
+        const int u = tid + it * 256;
+        const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
+        bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h + (size_t)(out_row0 + i) * out_stride_s;
+        if (MODE == 0) {
+            *reinterpret_cast<u32x4*>(orow + 8 * c) = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
+        } else if (MODE == 1) {
+            // NeoX half split: unit c pairs elements [8c, 8c+8) with [64+8c, 64+8c+8)
             u32x4 x1 = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
             u32x4 x2 = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + 128 + c * 16);
-            u32x4 cc = *reinterpret_cast<const u32x4*>(cs + 8 * c);
-            u32x4 ss = *reinterpret_cast<const u32x4*>(cs + 64 + 8 * c);
             u32x4 o1, o2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a0 = bf_lo(x1[j]), a1 = bf_hi(x1[j]), b0 = bf_lo(x2[j]), b1 = bf_hi(x2[j]);
-                float c0 = bf_lo(cc[j]), c1 = bf_hi(cc[j]), s0 = bf_lo(ss[j]), s1 = bf_hi(ss[j]);
-                float r0 = bfr(a0 * c0) + bfr(-b0 * s0), r1 = bfr(a1 * c1) + bfr(-b1 * s1);
-                float t0 = bfr(b0 * c0) + bfr(a0 * s0), t1 = bfr(b1 * c1) + bfr(a1 * s1);
-                o1[j] = pack_bf2(r0, r1);
-                o2[j] = pack_bf2(t0, t1);
+                float c0 = bf_lo(ecos[it][j]), c1 = bf_hi(ecos[it][j]), s0 = bf_lo(esin[it][j]), s1 = bf_hi(esin[it][j]);
+                o1[j] = pack_bf2(bfr(a0 * c0) + bfr(-b0 * s0), bfr(a1 * c1) + bfr(-b1 * s1));
+                o2[j] = pack_bf2(bfr(b0 * c0) + bfr(a0 * s0), bfr(b1 * c1) + bfr(a1 * s1));
             }
-            bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
-                           (size_t)(out_row0 + i) * out_stride_s;
             *reinterpret_cast<u32x4*>(orow + 8 * c) = o1;
             *reinterpret_cast<u32x4*>(orow + 64 + 8 * c) = o2;
-        }
-    } else {
-        // GLM: dims 0..63 interleaved pairs (2t, 2t+1) with cos = cs[t], sin = cs[32+t]; 64..127 copied
-        for (int u = tid; u < RB_ROWS * 16; u += 256) {
-            int row = u >> 4, c = u & 15, i = i0 + row;
-            if (i >= total_rows || i < cnt * C) continue;
+        } else {
+            // GLM: dims 0..63 interleaved pairs (2t, 2t+1) with cos = cs[t], sin = cs[32+t]; 64..127 copied
             u32x4 x = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
             u32x4 o = x;
             if (c < 8) {
-                long long id = ids64 ? ((const int64_t*)ids)[(size_t)bh * S + i / C]
-                                     : (long long)((const int32_t*)ids)[(size_t)bh * S + i / C];
-                long long p = id * C + i % C;
-                const bf16_t* cs = cos_sin + p * cs_stride;
-                u32x2 cc = *reinterpret_cast<const u32x2*>(cs + 4 * c);       // cos[4c .. 4c+3]
-                u32x2 ss = *reinterpret_cast<const u32x2*>(cs + 32 + 4 * c);  // sin[4c .. 4c+3]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float xe = bf_lo(x[j]), xo = bf_hi(x[j]);
-                    uint32_t cw = cc[j >> 1], sw = ss[j >> 1];
+                    uint32_t cw = ecos[it][j >> 1], sw = esin[it][j >> 1];
                     float cv = (j & 1) ? bf_hi(cw) : bf_lo(cw);
                     float sv = (j & 1) ? bf_hi(sw) : bf_lo(sw);
-                    float oe = bfr(xe * cv) + bfr(-xo * sv);
-                    float oo = bfr(xo * cv) + bfr(xe * sv);
-                    o[j] = pack_bf2(oe, oo);
+                    o[j] = pack_bf2(bfr(xe * cv) + bfr(-xo * sv), bfr(xo * cv) + bfr(xe * sv));
                 }
             }
-            bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
-                           (size_t)(out_row0 + i) * out_stride_s;
             *reinterpret_cast<u32x4*>(orow + 8 * c) = o;
         }
     }
@@ -179,23 +186,28 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, hipStream_t st) {
-    if (head_dim != RB_D || R % 32 != 0 || R < 32 || R > 256 || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
+    if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
+    if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
     if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
-    if (mode == 1 && cs_stride < 128) return SKV_ERR_ARG;
-    if (mode == 2 && cs_stride < 64) return SKV_ERR_ARG;
-    // LDS pitch is fixed for R <= 160; larger ranks need a wider pitch
-    if (R > 160) return SKV_ERR_UNSUPPORTED;
+    if (mode == 1 && (cs_stride < 128 || cs_stride % 8)) return SKV_ERR_ARG;
+    if (mode == 2 && (cs_stride < 64 || cs_stride % 4)) return SKV_ERR_ARG;
+    if (mode < 0 || mode > 2) return SKV_ERR_ARG;
     const int tiles = (S * C + RB_ROWS - 1) / RB_ROWS;
     const size_t smem = RB_D * RB_SV_PITCH + RB_ROWS * RB_OUT_PITCH;
     dim3 grid(tiles, bs * heads), block(256);
-#define SKV_RB(M)                                                                                                  \
-    hipLaunchKernelGGL((skv_rebuild_kernel<M>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,        \
-                       (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, R, S, C, ids64, cs_stride, \
+#define SKV_RB(M, K)                                                                                               \
+    hipLaunchKernelGGL((skv_rebuild_kernel<M, K>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,     \
+                       (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, ids64, cs_stride,    \
                        out_stride_b, out_stride_h, out_stride_s, out_row0)
-    if (mode == 0) SKV_RB(0);
-    else if (mode == 1) SKV_RB(1);
-    else if (mode == 2) SKV_RB(2);
-    else return SKV_ERR_ARG;
+#define SKV_RB_K(M)                 \
+    switch (R / 32) {               \
+        case 5: SKV_RB(M, 5); break; \
+        case 4: SKV_RB(M, 4); break; \
+        case 3: SKV_RB(M, 3); break; \
+        default: SKV_RB(M, 2); break; \
+    }
+    if (mode == 0) { SKV_RB_K(0) } else if (mode == 1) { SKV_RB_K(1) } else { SKV_RB_K(2) }
+#undef SKV_RB_K
 #undef SKV_RB
     return SKV_OK;
 }

@@ -16,12 +16,15 @@
 #include "skv_common.h"
 
 #define SKV_TILE 256  // columns per partial tile == the reference's ThreadblockShape::kN
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
 // K1: scoring.  One workgroup (4 waves) per 256-landmark tile.  A wave-instruction loads
 // 4 landmark rows (16 lanes x 16 B each, 1 KiB coalesced); lane `sub` of a row holds the
 // 8 contiguous elements k = 8*sub..8*sub+7, multiplies them into G running sums (q lives
-// in registers), and a 4-step butterfly over the 16 lanes finishes the dot product.
+// in registers, two query heads per v_pk_fma_f32), and a 4-step DPP butterfly over the 16
+// lanes finishes the dot products; the butterfly transposes (each lane finishes ONE of the G
+// totals), so scaling, bf16 rounding and the LDS store happen once per lane, not G times.
 // 16 loads (64 rows per wave) are issued before the first use.
 // ---------------------------------------------------------------------------------------
 template <int G>
@@ -40,14 +43,17 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
     __shared__ unsigned long long s_red_s[4][G];
     __shared__ float s_m[G];
 
-    float qf[G][8];
+    // q fragment: G x 8 floats, packed in pairs of query heads for v_pk_fma_f32
+    constexpr int GP = (G + 1) / 2;
+    f32x2 qf[GP][8];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        u32x4 w = *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + g) * 128 + 8 * sub);
+    for (int gp = 0; gp < GP; ++gp) {
+        u32x4 w0 = *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp) * 128 + 8 * sub);
+        u32x4 w1 = (2 * gp + 1 < G) ? *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp + 1) * 128 + 8 * sub) : w0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            qf[g][2 * j] = bf_lo(w[j]);
-            qf[g][2 * j + 1] = bf_hi(w[j]);
+            qf[gp][2 * j] = (f32x2){bf_lo(w0[j]), bf_lo(w1[j])};
+            qf[gp][2 * j + 1] = (f32x2){bf_hi(w0[j]), bf_hi(w1[j])};
         }
     }
 
@@ -59,6 +65,8 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
         row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
         x[i] = *reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub);
     }
+    const int my_g = row16_owner<G>(lane);
+    const bool publish = row16_publisher<G>(lane);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float xf[8];
@@ -67,15 +75,19 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
             xf[2 * j] = bf_lo(x[i][j]);
             xf[2 * j + 1] = bf_hi(x[i][j]);
         }
+        // per-lane partials: sequential fma chain over the lane's 8 elements, two heads per instruction
+        f32x2 acc2[GP];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float acc = 0.0f;
+        for (int gp = 0; gp < GP; ++gp) {
+            acc2[gp] = (f32x2){0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(qf[g][j], xf[j], acc);
-            acc = row16_tree_sum(acc);
-            bf16_t d = f2bf(alpha * acc);
-            if (sub == (g & 15)) sD[g][wave * 64 + i * 4 + rsel] = d;
+            for (int j = 0; j < 8; ++j) acc2[gp] = __builtin_elementwise_fma(qf[gp][j], (f32x2){xf[j], xf[j]}, acc2[gp]);
         }
+        float part[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) part[g] = (g & 1) ? acc2[g / 2].y : acc2[g / 2].x;
+        const float tot = row16_tree_sum_transposed<G>(part, lane);
+        if (publish) sD[my_g][wave * 64 + i * 4 + rsel] = f2bf(alpha * tot);
     }
     __syncthreads();
 
@@ -160,7 +172,8 @@ __global__ __launch_bounds__(256) void skv_softmax_apply_kernel(const bf16_t* __
 template <int G>
 __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
     const bf16_t* __restrict__ D, const float* __restrict__ part_max, const float* __restrict__ part_sum,
-    bf16_t* __restrict__ P /* nullable, [B][G][N] */, bf16_t* __restrict__ score /* [B][N] */, int N, int T) {
+    bf16_t* __restrict__ P /* nullable, [B][G][N] */, bf16_t* __restrict__ score /* [B][score_stride] */, int N, int T,
+    int score_stride) {
     const int b = blockIdx.y, t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_m[G], s_inv[G];
@@ -183,120 +196,199 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
         if (P) P[o] = p;
         best = p > best ? p : best;  // p >= 0: unsigned order == float order
     }
-    score[(size_t)b * N + col] = best;
+    score[(size_t)b * score_stride + col] = best;
 }
 
 // ---------------------------------------------------------------------------------------
 // K2b: top-k + diff.  One 1024-thread workgroup per (batch, kv head).
+//   1. the bf16 score row (N*2 bytes, 31 KB at the headline config) is staged into LDS with 16-B
+//      loads, so the three selection passes never wait on global latency;
+//   2. exact k-th value by two 256-bin histograms (high byte, then low byte) - scores are
+//      non-negative, so the bf16 pattern orders like the value; the bin search is done by one wave;
+//   3. ordered compaction: each thread owns a contiguous index range, one packed block scan gives
+//      every element its output position (ties at the threshold go to the lowest index);
+//   4. diff against the resident set through an LDS hash set, hits ordered by old slot with a
+//      counting pass, misses ordered by chunk id with a rank sort (S^2/1024 compares per thread).
 // ---------------------------------------------------------------------------------------
 #define SKV_SEL_THREADS 1024
 
-// inclusive scan of one int per thread over the 1024-thread workgroup
-__device__ __forceinline__ int block_scan_incl(int v, int* s_wave /*[16]*/, int tid) {
+// inclusive scan of two ints per thread over the 1024-thread workgroup (same barriers for both)
+__device__ __forceinline__ void block_scan_incl2(int& a, int& b, int* s_wave /*[32]*/, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        int n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
+        int na = __shfl_up(a, o, 64), nb = __shfl_up(b, o, 64);
+        if (lane >= o) {
+            a += na;
+            b += nb;
+        }
     }
-    if (lane == 63) s_wave[wave] = v;
+    if (lane == 63) {
+        s_wave[wave] = a;
+        s_wave[16 + wave] = b;
+    }
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 32) {
         int w = s_wave[tid];
+        const int l16 = tid & 15;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
-            int n = __shfl_up(w, o, 64);
-            if (tid >= o) w += n;
+            int n = __shfl_up(w, o, 16);
+            if (l16 >= o) w += n;
         }
         s_wave[tid] = w;
     }
     __syncthreads();
-    int base = wave > 0 ? s_wave[wave - 1] : 0;
-    __syncthreads();  // s_wave may be reused by the next call
-    return v + base;
-}
-
-// Given a 256-bin histogram in LDS (ascending key order), find the bin holding the k-th
-// LARGEST element.  Returns bin in *bin_out and the number of elements in higher bins in
-// *above_out (both broadcast through LDS).  Threads 0..255 participate; all must call.
-__device__ __forceinline__ void select_bin_desc(const int* hist, int k, int* s_wave, int* s_out, int tid) {
-    int c = tid < 256 ? hist[255 - tid] : 0;  // descending
-    int incl = block_scan_incl(c, s_wave, tid);
-    if (tid < 256 && incl >= k && incl - c < k) {
-        s_out[0] = 255 - tid;
-        s_out[1] = incl - c;
+    if (wave > 0) {
+        a += s_wave[wave - 1];
+        b += s_wave[16 + wave - 1];
     }
-    __syncthreads();
+    __syncthreads();  // s_wave is reused by the next call
 }
 
+// Wave 0 only: given a 256-bin histogram (ascending key order) find the bin holding the k-th
+// LARGEST element; s_out[0] = bin, s_out[1] = number of elements in higher bins.
+__device__ __forceinline__ void select_bin_desc_wave0(const int* hist, int k, int* s_out, int lane) {
+    int c[4], t = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = hist[255 - (4 * lane + j)];
+        t += c[j];
+    }
+    int incl = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    int run = incl - t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (run < k && run + c[j] >= k) {
+            s_out[0] = 255 - (4 * lane + j);
+            s_out[1] = run;
+        }
+        run += c[j];
+    }
+}
+
+// hist[bin] += 1 for every lane with `valid`, wave-aggregated: softmax scores of a long context are
+// nearly uniform, so most lanes hit the SAME bin and plain LDS atomics would serialise 64-way.  Two
+// rounds peel off the two most common bins of the wave with one atomic each, the rest add singly.
+__device__ __forceinline__ void hist_add_aggregated(int* hist, int bin, bool valid, int lane) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (valid) {
+            const int b0 = __builtin_amdgcn_readfirstlane(bin);
+            const bool same = bin == b0;
+            const unsigned long long m = __ballot(same);
+            if (same) {
+                if (lane == __ffsll((long long)m) - 1) atomicAdd(&hist[b0], __popcll(m));
+                valid = false;
+            }
+        }
+    }
+    if (valid) atomicAdd(&hist[bin], 1);
+}
+
+template <bool STAGE_LDS>
 __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
-    const bf16_t* __restrict__ score,      // [B][N] (nullable: then cur_in is used)
+    const bf16_t* __restrict__ score,      // [B][score_stride] (nullable: then cur_in is used)
     const int64_t* __restrict__ lm_idx,    // [B][N] slot -> chunk id (nullable: identity)
     const int64_t* __restrict__ cur_in,    // [B][S] ids selected by the caller (legacy path)
     int64_t* __restrict__ cached,          // [B][S] in: resident ids per slot; out: reordered ids
     int32_t* __restrict__ offsets,         // [B][S] out
     int32_t* __restrict__ cnts,            // [B] out
     int64_t* __restrict__ sel_out,         // [B][S] nullable: ids selected this step, ascending slot
-    int N, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
+    int N, int score_stride, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_cur = smem;            // [SP]
     int* s_hkeys = s_cur + SP;    // [H]
     int* s_hvals = s_hkeys + H;   // [H]
     int* s_byslot = s_hvals + H;  // [SP]  hit key by old slot, -1 if none
-    int* s_sortk = s_byslot + SP; // [SP]  misses (sorted in place)
-    int* s_hist = s_sortk + SP;   // [256]
-    int* s_wave = s_hist + 256;   // [16]
-    int* s_out = s_wave + 16;     // [4]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    int* s_miss = s_byslot + SP;  // [SP]  misses in selection order
+    int* s_rank = s_miss + SP;    // [SP]
+    int* s_hist = s_rank + SP;    // [256]
+    int* s_wave = s_hist + 256;   // [32]
+    int* s_out = s_wave + 32;     // [8]
+    bf16_t* s_score = reinterpret_cast<bf16_t*>(s_out + 8);  // [score_stride] when STAGE_LDS
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (score != nullptr) {
-        const bf16_t* sc = score + (size_t)b * N;
-        // ---- pass 1: histogram of the high byte
+        const bf16_t* gsc = score + (size_t)b * score_stride;
+        const u32x4* gvec = reinterpret_cast<const u32x4*>(gsc);
+        const u32x4* svec = STAGE_LDS ? reinterpret_cast<const u32x4*>(s_score) : gvec;
+        const int nvec = score_stride / 8;
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
-        for (int j = tid; j < N; j += SKV_SEL_THREADS) atomicAdd(&s_hist[sc[j] >> 8], 1);
+        // ---- pass 1: histogram of the high byte, fused with the staging copy
+        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
+            const u32x4 v = gvec[i];
+            if (STAGE_LDS) reinterpret_cast<u32x4*>(s_score)[i] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                hist_add_aggregated(s_hist, val >> 8, i * 8 + e < N, lane);
+            }
+        }
         __syncthreads();
-        select_bin_desc(s_hist, S, s_wave, s_out, tid);
+        if (wave == 0) select_bin_desc_wave0(s_hist, S, s_out, lane);
+        __syncthreads();
         const int hi = s_out[0], above_hi = s_out[1];
+        if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
         // ---- pass 2: histogram of the low byte inside that bin
-        if (tid < 256) s_hist[tid] = 0;
-        __syncthreads();
-        for (int j = tid; j < N; j += SKV_SEL_THREADS) {
-            bf16_t v = sc[j];
-            if ((v >> 8) == hi) atomicAdd(&s_hist[v & 0xff], 1);
-        }
-        __syncthreads();
-        select_bin_desc(s_hist, S - above_hi, s_wave, s_out, tid);
-        const int thr = (hi << 8) | s_out[0];
-        const int n_gt = above_hi + s_out[1];
-        const int need_eq = S - n_gt;
-        __syncthreads();
-        // ---- pass 3: ordered compaction; thread owns a contiguous index segment
-        const int seg = (N + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
-        const int j0 = tid * seg, j1 = min(j0 + seg, N);
-        int c_gt = 0, c_eq = 0;
-        for (int j = j0; j < j1; ++j) {
-            int v = sc[j];
-            c_gt += v > thr;
-            c_eq += v == thr;
-        }
-        int gt_before = block_scan_incl(c_gt, s_wave, tid) - c_gt;
-        int eq_before = block_scan_incl(c_eq, s_wave, tid) - c_eq;
-        for (int j = j0; j < j1; ++j) {
-            int v = sc[j];
-            int pos = -1;
-            if (v > thr) {
-                pos = gt_before + min(eq_before, need_eq);
-                ++gt_before;
-            } else if (v == thr) {
-                if (eq_before < need_eq) pos = gt_before + eq_before;
-                ++eq_before;
+        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
+            const u32x4 v = svec[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                hist_add_aggregated(s_hist, val & 0xff, (i * 8 + e < N) && ((val >> 8) == hi), lane);
             }
-            if (pos >= 0) {
-                long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
-                s_cur[pos] = (int)id;
-                if (sel_out) sel_out[(size_t)b * S + pos] = id;
+        }
+        __syncthreads();
+        if (wave == 0) select_bin_desc_wave0(s_hist, S - above_hi, s_out + 2, lane);
+        __syncthreads();
+        const int thr = (hi << 8) | s_out[2];
+        const int need_eq = S - (above_hi + s_out[3]);
+        // ---- pass 3: ordered compaction; thread owns `segv` consecutive 8-element vectors
+        const int segv = (nvec + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
+        const int v0 = min(tid * segv, nvec), v1 = min(v0 + segv, nvec);
+        int c_gt = 0, c_eq = 0;
+        for (int i = v0; i < v1; ++i) {
+            const u32x4 v = svec[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                const bool in = i * 8 + e < N;
+                c_gt += in && val > thr;
+                c_eq += in && val == thr;
+            }
+        }
+        int gt_before = c_gt, eq_before = c_eq;
+        block_scan_incl2(gt_before, eq_before, s_wave, tid);
+        gt_before -= c_gt;
+        eq_before -= c_eq;
+        for (int i = v0; i < v1; ++i) {
+            const u32x4 v = svec[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                const int j = i * 8 + e;
+                if (j >= N) continue;
+                int pos = -1;
+                if (val > thr) {
+                    pos = gt_before + min(eq_before, need_eq);
+                    ++gt_before;
+                } else if (val == thr) {
+                    if (eq_before < need_eq) pos = gt_before + eq_before;
+                    ++eq_before;
+                }
+                if (pos >= 0) {
+                    long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
+                    s_cur[pos] = (int)id;
+                    if (sel_out) sel_out[(size_t)b * S + pos] = id;
+                }
             }
         }
     } else {
@@ -308,7 +400,10 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         s_hkeys[i] = -1;
         s_hvals[i] = 0x7fffffff;
     }
-    for (int i = tid; i < SP; i += SKV_SEL_THREADS) s_byslot[i] = -1;
+    for (int i = tid; i < SP; i += SKV_SEL_THREADS) {
+        s_byslot[i] = -1;
+        s_rank[i] = 0;
+    }
     __syncthreads();
     if (tid < S) {
         int key = (int)cached[(size_t)b * S + tid];
@@ -344,46 +439,43 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         if (my_slot >= 0) s_byslot[my_slot] = my_key;
     }
     __syncthreads();
-    // hits ordered by old slot: compaction of s_byslot
+    // hits ordered by old slot (compaction of s_byslot), misses in selection order
     const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
-    const int hit_incl = block_scan_incl(is_hit_slot, s_wave, tid);
-    if (tid == SKV_SEL_THREADS - 1) s_out[2] = hit_incl;
-    // misses in selection order, then sorted by id
     const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
-    const int miss_incl = block_scan_incl(is_miss, s_wave, tid);
+    int hit_incl = is_hit_slot, miss_incl = is_miss;
+    block_scan_incl2(hit_incl, miss_incl, s_wave, tid);
+    if (tid == SKV_SEL_THREADS - 1) {
+        s_out[4] = hit_incl;
+        s_out[5] = miss_incl;
+    }
+    if (is_miss) s_miss[miss_incl - 1] = my_key;
     __syncthreads();
-    const int cnt = s_out[2];
-    for (int i = tid; i < SP; i += SKV_SEL_THREADS) s_sortk[i] = 0x7fffffff;
-    __syncthreads();
-    if (is_miss) s_sortk[miss_incl - 1] = my_key;
-    __syncthreads();
-    // bitonic sort of s_sortk[0..SP) ascending (signed)
-    for (int size = 2; size <= SP; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < SP; i += SKV_SEL_THREADS) {
-                int ixj = i ^ stride;
-                if (ixj > i) {
-                    bool asc = (i & size) == 0;
-                    int a = s_sortk[i], c = s_sortk[ixj];
-                    if ((a > c) == asc) {
-                        s_sortk[i] = c;
-                        s_sortk[ixj] = a;
-                    }
-                }
+    const int cnt = s_out[4], nm = s_out[5];
+    // rank sort of the misses by chunk id (ties by position): P threads share one element
+    {
+        const int P = SKV_SEL_THREADS / SP;
+        const int i = tid / P, part = tid % P;
+        if (i < nm) {
+            const int ki = s_miss[i];
+            int r = 0;
+            for (int j = part; j < nm; j += P) {
+                int kj = s_miss[j];
+                r += (kj < ki) || (kj == ki && j < i);
             }
-            __syncthreads();
+            if (r) atomicAdd(&s_rank[i], r);
         }
     }
+    __syncthreads();
     // ---- write out
     if (is_hit_slot) {
         int o = hit_incl - 1;
         cached[(size_t)b * S + o] = (long long)s_byslot[tid];
         offsets[(size_t)b * S + o] = tid;
     }
-    if (tid < S - cnt) {
-        int key = s_sortk[tid];
-        cached[(size_t)b * S + cnt + tid] = (long long)key;
-        offsets[(size_t)b * S + cnt + tid] = key;
+    if (tid < nm) {
+        int key = s_miss[tid], o = cnt + s_rank[tid];
+        cached[(size_t)b * S + o] = (long long)key;
+        offsets[(size_t)b * S + o] = key;
     }
     if (tid == 0) cnts[b] = cnt;
 }
@@ -427,12 +519,12 @@ int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void
     return SKV_OK;
 }
 
-int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score, int B,
-                                  int G, int N, hipStream_t st) {
+int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
+                                  int score_stride, int B, int G, int N, hipStream_t st) {
     const int T = (N + SKV_TILE - 1) / SKV_TILE;
 #define SKV_NG(GG)                                                                                              \
     hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(T, B), dim3(256), 0, st, (const bf16_t*)D, pmax, \
-                       psum, (bf16_t*)P, (bf16_t*)score, N, T)
+                       psum, (bf16_t*)P, (bf16_t*)score, N, T, score_stride)
     switch (G) {
         case 1: SKV_NG(1); break;
         case 2: SKV_NG(2); break;
@@ -445,15 +537,32 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
     return SKV_OK;
 }
 
-int skv_launch_topk_reorder(const void* score, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
-                            int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
+int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
+                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
                             hipStream_t st) {
     if (S < 1 || S > SKV_SEL_THREADS) return SKV_ERR_UNSUPPORTED;
-    if (score != nullptr && N < S) return SKV_ERR_ARG;
+    if (score != nullptr && (N < S || score_stride < N || (score_stride % 8))) return SKV_ERR_ARG;
     const int SP = next_pow2(S);
     const int H = 4 * SP;
-    const size_t smem = (size_t)(SP * 3 + H * 2 + 256 + 16 + 4) * sizeof(int);
-    hipLaunchKernelGGL(skv_topk_reorder_kernel, dim3(B), dim3(SKV_SEL_THREADS), smem, st, (const bf16_t*)score,
-                       lm_idx, cur_in, cached, offsets, cnts, sel_out, N, S, H, SP);
+    const size_t base = (size_t)(SP * 4 + H * 2 + 256 + 32 + 8) * sizeof(int);
+    const size_t with_score = base + (size_t)score_stride * sizeof(bf16_t);
+    const bool stage = score != nullptr && with_score <= 150 * 1024;
+    const size_t smem = stage ? with_score : base;
+    if (stage) {
+        static size_t attr_bytes = 0;
+        if (smem > 64 * 1024 && smem > attr_bytes) {
+            if (hipFuncSetAttribute((const void*)skv_topk_reorder_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return SKV_ERR_LAUNCH;
+            attr_bytes = 150 * 1024;
+        }
+        hipLaunchKernelGGL(skv_topk_reorder_kernel<true>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
+                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, N, score_stride, S, H,
+                           SP);
+    } else {
+        hipLaunchKernelGGL(skv_topk_reorder_kernel<false>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
+                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, N, score_stride, S, H,
+                           SP);
+    }
     return SKV_OK;
 }

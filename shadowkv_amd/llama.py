@@ -273,3 +273,125 @@ class QueryWalk:
 
     def __call__(self, layer_idx, q_model):
         return torch.addcmul(self.qb[layer_idx], q_model, torch.zeros((), device=q_model.device, dtype=q_model.dtype))
+
+
+class GraphDecoder:
+    """One decode step (embedding -> all layers -> sampling) captured once into a hipGraph and replayed.
+
+    Same operations, same kernels, same order and the same two-stream overlap as DecoderLM.decode_step;
+    only what changes from step to step moves from host integers into device memory so the captured
+    launch sequence stays valid:
+        token     int64 [bs,1]   input token (the previous step's sample is written back into it)
+        pos       int64 [bs,1]   RoPE position of the new token            (= kv_cache.kv_offset)
+        row_idx   int64 [1]      buffer row the new K/V go to              (= sparse_end + gen_offset)
+        kv_len    int32 [1]      rows attended                              (= sparse_end + gen_offset + 1)
+        step      int64 [1]      index into the synthetic query table (bench only)
+    At bs = 1 a decode step is ~25 launches per layer; eager PyTorch is host-bound on that
+    (MI355X_MICROARCH.md "graph-replay-floor"), the graph removes the per-launch host cost."""
+
+    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None):
+        self.m = model
+        self.temperature, self.top_p, self.top_k = temperature, top_p, top_k
+        c = model.kv_cache
+        dev = model.device
+        self.slack = c.k_cache_buffer.shape[-2] - c.sparse_end
+        self.token = torch.zeros(model.batch_size, 1, dtype=torch.long, device=dev)
+        self.pos = torch.full((model.batch_size, 1), c.kv_offset, dtype=torch.long, device=dev)
+        self.gen = torch.full((1,), c.gen_offset, dtype=torch.long, device=dev)
+        self.row_idx = self.gen + c.sparse_end
+        self.kv_len = (self.row_idx + 1).to(torch.int32)
+        self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        self.walk_table = walk_table                     # [T, L, bs, Hq, 1, D] or None
+        self._zero = torch.zeros((), device=dev, dtype=model.dtype)
+        self.graph = None
+
+    def _sample(self, logits):
+        if self.temperature == 0.0:
+            return logits.argmax(dim=-1, keepdim=True)
+        logits = logits / self.temperature
+        if self.top_k > 0:
+            kth = torch.topk(logits, min(self.top_k, logits.size(-1)))[0][:, -1:]
+            logits = logits.masked_fill(logits < kth, float("-inf"))
+        if self.top_p > 0.0:
+            sl, si = torch.sort(logits, descending=True)
+            rm = torch.cumsum(F.softmax(sl, dim=-1), dim=-1) > self.top_p
+            rm = torch.cat((torch.zeros_like(rm[..., :1]), rm[..., :-1]), dim=-1)
+            logits = logits.masked_fill(torch.zeros_like(rm).scatter(1, si, rm), float("-inf"))
+        probs = F.softmax(logits, dim=-1)
+        # multinomial(1) as torch implements it: argmax(p / Exp(1)), without host-side checks
+        return torch.argmax(probs / torch.empty_like(probs).exponential_(1.0), dim=-1, keepdim=True)
+
+    def _body(self):
+        m, c = self.m, self.m.kv_cache
+        hs = F.embedding(self.token, m.embed_tokens)
+        qstep = None
+        if self.walk_table is not None:
+            qstep = torch.index_select(self.walk_table, 0, self.step_idx)[0]
+        cur = torch.cuda.current_stream()
+        side = c.copy_stream
+        for l, layer in enumerate(m.layers):
+            residual = hs
+            q, k, v = m.pre_attention_compute(hs, layer)
+            q, k = m.apply_rotary_pos_emb(q, k, self.pos)
+            if qstep is not None:
+                q = torch.addcmul(qstep[l], q, self._zero)
+            c.k_cache_buffer[l].index_copy_(2, self.row_idx, k)
+            c.v_cache_buffer[l].index_copy_(2, self.row_idx, v)
+            ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+            with torch.cuda.stream(side):
+                side.wait_stream(cur)
+                c.get_value_cache(l, ids)
+            c.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=m.cos_sin_cache)
+            cur.wait_stream(side)
+            attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=0,
+                                                     kv_len_dev=self.kv_len)
+            hs = m.post_attention_compute(attn.reshape(hs.shape[0], 1, m.hidden_size), residual, layer)
+        hs = tensor_op.layer_norm(hs, m.norm_variance_epsilon, m.norm_weight)
+        logits = F.linear(hs, m.lm_head).float()
+        self.token.copy_(self._sample(logits[:, -1, :]))
+        # advance the device-side counters (generated-row slack wraps like the host bookkeeping in step())
+        self.pos.add_(1)
+        self.gen.copy_((self.gen + 1) % self.slack)
+        self.row_idx.copy_(self.gen + c.sparse_end)
+        self.kv_len.copy_((self.row_idx + 1).to(torch.int32))
+        if self.walk_table is not None:
+            self.step_idx.copy_((self.step_idx + 1) % self.walk_table.shape[0])
+
+    def _host_advance(self):
+        c = self.m.kv_cache
+        c.kv_offset += 1
+        c.gen_offset = (c.gen_offset + 1) % self.slack
+
+    @torch.inference_mode()
+    def capture(self, warmup=2):
+        s = torch.cuda.Stream(device=self.m.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):          # eager: sizes workspaces, sets kernel attributes, warms hipBLASLt
+                self._body()
+                self._host_advance()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize(self.m.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s):
+            self._body()
+        return warmup
+
+    @torch.inference_mode()
+    def step(self):
+        if self.graph is None:
+            self._body()
+        else:
+            self.graph.replay()
+        self._host_advance()
+        return self.token
+
+
+def make_walk_table(model, steps, step=0.3, q_scale=0.25, seed=99):
+    """[steps, L, bs, Hq, 1, D] bf16: the QueryWalk trajectory, precomputed so a captured graph can index it."""
+    w = QueryWalk(model, step=step, q_scale=q_scale, seed=seed)
+    out = []
+    for _ in range(steps):
+        w.advance()
+        out.append(w.qb.clone())
+    return torch.stack(out)

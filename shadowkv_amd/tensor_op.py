@@ -134,7 +134,7 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     if not q.is_contiguous():
         q = q.contiguous()
     if splits is None:
-        splits = max(1, min(64, 256 // max(1, bs * Hkv)))
+        splits = max(1, min(32, 256 // max(1, bs * Hkv)))
     key = (q.device.index, bs, Hq, splits)
     ws = _attn_ws.get(key)
     if ws is None:

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names, "ctypes signature table out of sync with the header"
     assert _lib.lib().skv_abi_version() == 1
     assert _lib.lib().skv_select_workspace_bytes(8, 4, 15560) > 0
-    assert _lib.lib().skv_attn_workspace_bytes(1, 32, 32) == 32 * 32 * 130 * 4
+    assert _lib.lib().skv_attn_workspace_bytes(1, 32, 32) == 32 * 32 * 132 * 4
 
 
 def test_header_compiles_as_plain_c():
