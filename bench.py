@@ -250,8 +250,6 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
             mode = "eager"
             dec = None
-    if mode == "eager" and args.query_mode == "walk":
-        model.query_hook = walk
 
     def step():
         nonlocal next_token
@@ -263,7 +261,8 @@ def main():
                 cache.kv_offset = ctx                 # bookkeeping instead so every step does full work
             if args.query_mode == "walk":
                 walk.advance()
-            next_token = model.decode_step(next_token, temperature=0.6)
+            next_token = model.decode_step(next_token, temperature=0.6,
+                                           q_table=walk.qb if args.query_mode == "walk" else None)
         tokens.append(next_token[:, -1].tolist())     # per-step host sync, as base.py:635
 
     for _ in range(args.warmup):

@@ -188,6 +188,30 @@ SKV_EXPORT int skv_sparse_attention(const void* q, const void* k, const void* v,
                          const int32_t* kv_len_dev, int kv_len, long long kv_head_stride, int batch_size,
                          int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Part 3: small fused host-model ops of the decode step (what sits between the dense projections and
+ * the ShadowKV kernels in LLM.layer_compute, /root/reference/models/base.py:315-341)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Split the fused QKV projection of ONE new token per sequence (qkv [bs][(q_heads+2*kv_heads)*128]), rotate
+ * q and k at pos[b] (rope_mode 1 = NeoX / Llama, 2 = GLM), write q [bs][q_heads][128] and push k, v into
+ * row *row_idx of the cache buffers [bs][kv_heads][cache_rows][128].  Replaces vllm rotary_embedding
+ * (/root/reference/models/llama.py:296) + ShadowKVCache_CPU.update_kv_cache (kv_cache.py:1227-1271); rows
+ * outside [0, cache_rows) are dropped like the reference's zero-length slice.  q_override (nullable): values
+ * written to q instead of the rotated projection (synthetic-query benchmarking). */
+SKV_EXPORT int skv_qkv_rope_update(const void* qkv, const void* cos_sin, const int64_t* pos, const int64_t* row_idx,
+                        const void* q_override, void* q_out, void* k_cache, void* v_cache, int batch_size,
+                        int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, long long cache_stride_b,
+                        long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
+
+/* h = x + residual (bf16; residual may be NULL), y = RMSNorm(h) * weight (flashinfer.norm.rmsnorm,
+ * /root/reference/models/tensor_op.py:34-39).  h_out nullable. */
+SKV_EXPORT int skv_add_rmsnorm(const void* x, const void* residual, const void* weight, void* h_out, void* y, int rows,
+                    int hidden, float eps, skv_stream_t stream);
+
+/* out[r][i] = silu(x[r][i]) * x[r][inter+i]  (vllm._custom_ops.silu_and_mul, llama.py:421) */
+SKV_EXPORT int skv_silu_and_mul(const void* x, void* out, int rows, int inter, skv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,6 +268,12 @@ class ShadowKVCache_CPU:
                                self.sparse_start, self.chunk_size)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
+    def note_kv_appended(self, incoming=1):
+        """Bookkeeping half of update_kv_cache for callers that wrote the new K / V rows themselves
+        (tensor_op.qkv_rope_update pushes them from the fused QKV kernel): advances the offsets once per token."""
+        self.kv_offset += incoming
+        self.gen_offset += incoming
+
     def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
         """Appends the new token's K / V after the sparse region (kv_cache.py:1227-1271); rows past
         the end of the buffer are dropped exactly as the reference's zero-length slice does."""

@@ -180,6 +180,44 @@ class DecoderLM:
         attn = tensor_op.sparse_attention_decode(q, k_view, v_view)
         return self.post_attention_compute(attn.reshape(bsz, q_len, self.hidden_size), residual, layer)
 
+    # --------------------------------------------------------------- fused decode step (MI355X launch sequence)
+    @torch.inference_mode()
+    def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
+        """Same computation as inference() for q_len == 1, with the small ops fused and the step's
+        scalars in device memory (graph-capturable): 16 launches per layer instead of ~40.
+          token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
+          kv_len / kv_len_dev: rows attended (= row_idx + 1), q_table: optional [L, bs, Hq, 1, D] synthetic queries.
+        Per layer: add+RMSNorm -> QKV GEMV -> split/RoPE/cache-push -> select -> [side stream: V move] ||
+        K move + rebuild -> attention -> O GEMV -> add+RMSNorm -> gate/up GEMV -> SiLU*mul -> down GEMV."""
+        c = self.kv_cache
+        x = F.embedding(token, self.embed_tokens)
+        residual = None
+        cur = torch.cuda.current_stream()
+        side = c.copy_stream
+        bs = x.shape[0]
+        c.incoming_q_len = 1
+        for l, layer in enumerate(self.layers):
+            residual, hs = tensor_op.add_rmsnorm(x, residual, layer.input_layernorm_weight,
+                                                 layer.input_layernorm_variance_epsilon)
+            qkv = F.linear(hs, layer.wqkv, layer.bqkv)
+            q = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l],
+                                          c.v_cache_buffer[l], self.num_heads, self.num_key_value_heads,
+                                          q_override=None if q_table is None else q_table[l])
+            ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+            with torch.cuda.stream(side):
+                side.wait_stream(cur)
+                c.get_value_cache(l, ids)
+            c.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=self.cos_sin_cache)
+            cur.wait_stream(side)
+            attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,
+                                                     kv_len_dev=kv_len_dev)
+            o = F.linear(attn.reshape(bs, 1, self.hidden_size), layer.wo)
+            residual, hs = tensor_op.add_rmsnorm(o, residual, layer.post_attention_layernorm_weight,
+                                                 layer.post_attention_layernorm_variance_epsilon)
+            x = F.linear(tensor_op.silu_and_mul_fused(F.linear(hs, layer.gate_up_proj)), layer.down_proj)
+        _, hs = tensor_op.add_rmsnorm(x, residual, self.norm_weight, self.norm_variance_epsilon)
+        return F.linear(hs, self.lm_head).float()
+
     def get_ctx(self, input_ids):
         past = self.kv_cache.get_kv_len()
         n = input_ids.size(1)
@@ -194,9 +232,18 @@ class DecoderLM:
         return F.linear(hs, self.lm_head).float()
 
     @torch.inference_mode()
-    def decode_step(self, next_token, temperature=0.6, top_p=0.9, top_k=50):
-        """One iteration of the reference's timed loop (base.py:628-635)."""
-        logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
+    def decode_step(self, next_token, temperature=0.6, top_p=0.9, top_k=50, q_table=None, fused=True):
+        """One iteration of the reference's timed loop (base.py:628-635).  fused=False runs the reference's
+        exact call order through the reference-shaped methods (inference / layer_compute)."""
+        if not fused:
+            logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
+        else:
+            c = self.kv_cache
+            row = c.sparse_end + c.gen_offset
+            pos = self.get_ctx(next_token)
+            row_idx = torch.tensor([row], device=self.device, dtype=torch.long)
+            logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table)
+            c.note_kv_appended(1)
         return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k)
 
 
@@ -323,31 +370,10 @@ class GraphDecoder:
 
     def _body(self):
         m, c = self.m, self.m.kv_cache
-        hs = F.embedding(self.token, m.embed_tokens)
         qstep = None
         if self.walk_table is not None:
             qstep = torch.index_select(self.walk_table, 0, self.step_idx)[0]
-        cur = torch.cuda.current_stream()
-        side = c.copy_stream
-        for l, layer in enumerate(m.layers):
-            residual = hs
-            q, k, v = m.pre_attention_compute(hs, layer)
-            q, k = m.apply_rotary_pos_emb(q, k, self.pos)
-            if qstep is not None:
-                q = torch.addcmul(qstep[l], q, self._zero)
-            c.k_cache_buffer[l].index_copy_(2, self.row_idx, k)
-            c.v_cache_buffer[l].index_copy_(2, self.row_idx, v)
-            ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
-            with torch.cuda.stream(side):
-                side.wait_stream(cur)
-                c.get_value_cache(l, ids)
-            c.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=m.cos_sin_cache)
-            cur.wait_stream(side)
-            attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=0,
-                                                     kv_len_dev=self.kv_len)
-            hs = m.post_attention_compute(attn.reshape(hs.shape[0], 1, m.hidden_size), residual, layer)
-        hs = tensor_op.layer_norm(hs, m.norm_variance_epsilon, m.norm_weight)
-        logits = F.linear(hs, m.lm_head).float()
+        logits = m.forward_fused(self.token, self.pos, self.row_idx, kv_len=0, kv_len_dev=self.kv_len, q_table=qstep)
         self.token.copy_(self._sample(logits[:, -1, :]))
         # advance the device-side counters (generated-row slack wraps like the host bookkeeping in step())
         self.pos.add_(1)

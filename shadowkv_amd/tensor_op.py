@@ -35,6 +35,41 @@ def silu_and_mul(out, x):
     return out
 
 
+def add_rmsnorm(x, residual, w, eps):
+    """(h, y): h = x + residual (bf16; residual None -> h = x), y = RMSNorm(h) * w.  One native launch."""
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    h = torch.empty_like(x2) if residual is not None else x2
+    y = torch.empty_like(x2)
+    check(lib().skv_add_rmsnorm(ptr(x2), ptr(residual.reshape(-1, shape[-1]) if residual is not None else None),
+                                ptr(w), ptr(h) if residual is not None else 0, ptr(y), x2.shape[0], shape[-1],
+                                float(eps), current_stream_handle()), "add_rmsnorm")
+    return h.view(shape), y.view(shape)
+
+
+def silu_and_mul_fused(x):
+    """silu(x[..., :d]) * x[..., d:] in one native launch (x contiguous)."""
+    d = x.shape[-1] // 2
+    out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+    check(lib().skv_silu_and_mul(ptr(x), ptr(out), x.numel() // x.shape[-1], d, current_stream_handle()),
+          "silu_and_mul")
+    return out
+
+
+def qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_heads, q_override=None):
+    """qkv [bs, 1, (Hq+2Hkv)*D] -> q [bs, Hq, 1, D] rotated at pos [bs] (int64, device); k (rotated) and v are
+    written into row row_idx[0] (int64, device) of k_cache / v_cache [bs, Hkv, rows, D].  One native launch."""
+    bs = qkv.shape[0]
+    D = k_cache.shape[-1]
+    width = cos_sin.shape[-1]
+    q = torch.empty(bs, q_heads, 1, D, dtype=qkv.dtype, device=qkv.device)
+    check(lib().skv_qkv_rope_update(ptr(qkv), ptr(cos_sin), ptr(pos), ptr(row_idx), ptr(q_override), ptr(q),
+                                    ptr(k_cache), ptr(v_cache), bs, q_heads, kv_heads, D, cos_sin.stride(0),
+                                    k_cache.stride(0), k_cache.stride(1), k_cache.shape[2], 1 if width == 128 else 2,
+                                    current_stream_handle()), "qkv_rope_update")
+    return q
+
+
 # ---------------------------------------------------------------------------- RoPE (pure torch, tensor_op.py:127-151)
 def rotate_half(x):
     half = x.shape[-1] // 2
