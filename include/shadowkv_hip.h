@@ -172,12 +172,28 @@ SKV_EXPORT int skv_move_chunks(const void* host_values, void* cache_buffer, cons
 /* ShadowKVCache_CPU.get_key_cache, rebuild part (kv_cache.py:1157-1168 -> models/tensor_op.py:201-238):
  * k_cache[b][h][sparse_start + i][:] = RoPE(bf16(U[b][pos(i)] . SV[b][h]^T), pos(i)) for chunks >= cnts.
  * chunk_ids int64 [bs][heads][select_sets] (the reordered cached_pos_ids); rope_mode 1 = Llama
- * (cos_sin width 128), 2 = GLM (width 64).  Cache strides in elements. */
+ * (cos_sin width 128), 2 = GLM (width 64).  Cache strides in elements.  hit_temp / hit_offsets (nullable):
+ * also land the moved hit chunks staged by skv_stage_hit_chunks (the K half of the two-phase compaction). */
 SKV_EXPORT int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,
                      const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
                      int rank, int select_sets, int chunk_size, long long cos_sin_stride,
                      long long cache_stride_b, long long cache_stride_h, long long cache_stride_s,
-                     int sparse_start, int rope_mode, skv_stream_t stream);
+                     int sparse_start, int rope_mode, const void* hit_temp, const int32_t* hit_offsets,
+                     skv_stream_t stream);
+
+/* Two-phase, spin-free form of skv_move_chunks used by the decode path:
+ *   skv_stage_hit_chunks: temp[b][i] <- cache[b][sparse + offsets[i]] for hit chunks whose slot changes, for
+ *                         the K and the V buffer in one launch (either may be NULL);
+ *   skv_land_chunks     : cache[b][sparse + i] <- temp[b][i] (moved hits) / host_values[b][offsets[i]] (misses;
+ *                         host_values NULL: hits only).
+ * For K, landing is folded into skv_rebuild_keys (hit_temp / hit_offsets, NULL = not used).  temp buffers are
+ * [blocks][select_sets][1024] bf16.  The launch boundary between the two phases is the only ordering needed. */
+SKV_EXPORT int skv_stage_hit_chunks(void* k_cache, void* k_temp, void* v_cache, void* v_temp, const int32_t* offsets,
+                         const int32_t* cnts, long long cache_block_stride, long long cache_sparse_offset, int blocks,
+                         int select_sets, skv_stream_t stream);
+SKV_EXPORT int skv_land_chunks(const void* host_values, void* cache_buffer, const void* temp, const int32_t* offsets,
+                    const int32_t* cnts, long long host_block_stride, long long cache_block_stride,
+                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream);
 
 /* Sparse decode attention (replaces flash_attn_with_kvcache at /root/reference/models/base.py:341 for
  * q_len == 1).  q [bs][q_heads][128], k/v [bs][kv_heads][rows][128] (kv_head_stride elements between heads),

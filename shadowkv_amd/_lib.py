@@ -40,7 +40,9 @@ _SIGS = {
     "skv_select_chunks": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f, c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
     "skv_move_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
-    "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p]),
+    "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
+    "skv_stage_hit_chunks": (c_int, [c_p] * 6 + [c_ll] * 2 + [c_int] * 2 + [c_p]),
+    "skv_land_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_attn_workspace_bytes": (c_sz, [c_int] * 3),
     "skv_qkv_rope_update": (c_int, [c_p] * 8 + [c_int] * 4 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_add_rmsnorm": (c_int, [c_p] * 5 + [c_int] * 2 + [c_f, c_p]),

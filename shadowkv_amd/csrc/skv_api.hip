@@ -24,7 +24,14 @@ int skv_launch_gather_rows(const void* host_rows, void* dev, const int64_t* ids,
 int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
-                       long long out_stride_s, int out_row0, int mode, hipStream_t st);
+                       long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
+                       hipStream_t st);
+int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
+                          const int32_t* cnts, long long stride_elems, long long off_elems, int B, int S,
+                          hipStream_t st);
+int skv_launch_land_rows(const void* host_rows, void* buf, const void* temp, const int32_t* offsets,
+                         const int32_t* cnts, long long host_len_elems, long long stride_elems, long long off_elems,
+                         int B, int S, hipStream_t st);
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
                                 const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
                                 int Hkv, int head_dim, int splits, float scale, hipStream_t st);
@@ -141,7 +148,8 @@ int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const v
     return finish(skv_launch_rebuild(a, b, nullptr, position_ids, 0, offset_array, output, batch_size, heads,
                                      seq_len, embed_dim, rank, sparse_budget / chunk_size, chunk_size, 0,
                                      (long long)heads * sparse_budget * embed_dim,
-                                     (long long)sparse_budget * embed_dim, embed_dim, 0, 0, (hipStream_t)stream));
+                                     (long long)sparse_budget * embed_dim, embed_dim, 0, 0, nullptr, nullptr,
+                                     (hipStream_t)stream));
 }
 
 #define SKV_ROPE_PUSH_ARGS                                                                                       \
@@ -259,13 +267,31 @@ int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const i
                      const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
                      int rank, int select_sets, int chunk_size, long long cos_sin_stride,
                      long long cache_stride_b, long long cache_stride_h, long long cache_stride_s,
-                     int sparse_start, int rope_mode, skv_stream_t stream) {
+                     int sparse_start, int rope_mode, const void* hit_temp, const int32_t* hit_offsets,
+                     skv_stream_t stream) {
     if (!U || !SV || !cos_sin || !chunk_ids || !cnts || !k_cache) return SKV_ERR_ARG;
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len,
                                      head_dim, rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b,
-                                     cache_stride_h, cache_stride_s, sparse_start, rope_mode,
+                                     cache_stride_h, cache_stride_s, sparse_start, rope_mode, hit_temp, hit_offsets,
                                      (hipStream_t)stream));
+}
+
+int skv_stage_hit_chunks(void* k_cache, void* k_temp, void* v_cache, void* v_temp, const int32_t* offsets,
+                         const int32_t* cnts, long long cache_block_stride, long long cache_sparse_offset, int blocks,
+                         int select_sets, skv_stream_t stream) {
+    if ((!k_cache && !v_cache) || (k_cache && !k_temp) || (v_cache && !v_temp) || !offsets || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_stage_hits(k_cache, k_temp, v_cache, v_temp, offsets, cnts, cache_block_stride,
+                                        cache_sparse_offset, blocks, select_sets, (hipStream_t)stream));
+}
+
+int skv_land_chunks(const void* host_values, void* cache_buffer, const void* temp, const int32_t* offsets,
+                    const int32_t* cnts, long long host_block_stride, long long cache_block_stride,
+                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream) {
+    if (!cache_buffer || !temp || !offsets || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_land_rows(host_values, cache_buffer, temp, offsets, cnts, host_block_stride,
+                                       cache_block_stride, cache_sparse_offset, blocks, select_sets,
+                                       (hipStream_t)stream));
 }
 
 int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const int32_t* __restrict__ cnts,    // [bs*heads] (nullable -> 0)
     bf16_t* __restrict__ out,            // MODE 0: [bs][heads][S*C][128]; else key cache
     int heads, int seq_len, int S, int C, int ids64, long long cs_stride,
-    long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0) {
+    long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0,
+    const bf16_t* __restrict__ hit_temp, // nullable: [bs*heads][S][C*128] moved hit chunks staged by skv_stage_hits
+    const int32_t* __restrict__ hit_offsets /* [bs*heads][S] */) {
     constexpr int R = KS * 32;
     constexpr int UNITS_PER_ROW = R / 8;                       // 16-B units per SV row
     constexpr int SV_ITERS = (RB_D * UNITS_PER_ROW + 255) / 256;
@@ -57,8 +59,29 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const int i0 = blockIdx.x * RB_ROWS;
     const int total_rows = S * C;
     const int cnt = cnts ? cnts[bh] : 0;
-    if (i0 + RB_ROWS <= cnt * C) return;  // every row of this tile is a resident (hit) row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (hit_temp != nullptr && C == 8) {
+        // second half of the two-phase compaction (skv_move.hip): land the moved hit chunks of this tile
+        // (chunk slot j < cnt whose source slot differs) from the staging buffer into their final rows.
+        const int j0 = i0 / 8;                       // first chunk slot of the tile (RB_ROWS / C = 8 slots)
+        const int unit = tid & 127, rsub = tid >> 7;
+        u32x4 hv[4];
+        bool hact[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k * 2 + rsub;
+            hact[k] = j < cnt && j < S && hit_offsets[(size_t)bh * S + j] != j;
+            if (hact[k]) hv[k] = reinterpret_cast<const u32x4*>(hit_temp)[((size_t)bh * S + j) * 128 + unit];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k * 2 + rsub;
+            if (hact[k])
+                reinterpret_cast<u32x4*>(out + (size_t)b * out_stride_b + (size_t)h * out_stride_h +
+                                         (size_t)(out_row0 + j * 8) * out_stride_s)[unit] = hv[k];
+        }
+    }
+    if (i0 + RB_ROWS <= cnt * C) return;  // every row of this tile is a resident (hit) row
 
     // ---- phase 1: issue every global load this workgroup needs
     // A fragments (gathered U rows)
@@ -185,20 +208,22 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
 int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
-                       long long out_stride_s, int out_row0, int mode, hipStream_t st) {
+                       long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
+                       hipStream_t st) {
     if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
     if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
     if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
     if (mode == 1 && (cs_stride < 128 || cs_stride % 8)) return SKV_ERR_ARG;
     if (mode == 2 && (cs_stride < 64 || cs_stride % 4)) return SKV_ERR_ARG;
     if (mode < 0 || mode > 2) return SKV_ERR_ARG;
+    if (hit_temp && (C != 8 || out_stride_s != 128 || !hit_offsets)) return SKV_ERR_UNSUPPORTED;
     const int tiles = (S * C + RB_ROWS - 1) / RB_ROWS;
     const size_t smem = RB_D * RB_SV_PITCH + RB_ROWS * RB_OUT_PITCH;
     dim3 grid(tiles, bs * heads), block(256);
 #define SKV_RB(M, K)                                                                                               \
     hipLaunchKernelGGL((skv_rebuild_kernel<M, K>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,     \
                        (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, ids64, cs_stride,    \
-                       out_stride_b, out_stride_h, out_stride_s, out_row0)
+                       out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets)
 #define SKV_RB_K(M)                 \
     switch (R / 32) {               \
         case 5: SKV_RB(M, 5); break; \

@@ -18,8 +18,9 @@ MI355X-first differences that do not change results:
   * U / SV / landmarks are created in HBM straight away (288 GB): H2D() only sizes the decode
     workspaces; the reference parks them on the CPU until H2D() (kv_cache.py:694-696, :1178-1225).
   * get_retrieval_position_ids is ONE native call (score + softmax + group max + top-k + diff,
-    no [bs,kv,G,N] round trips through torch.max / torch.topk / gather); get_key_cache is one
-    compaction launch + one fused rebuild-RoPE-store launch (no `output` round trip).
+    no [bs,kv,G,N] round trips through torch.max / torch.topk / gather) followed by the staging launch
+    of the chunk movement; get_key_cache is one fused landing + rebuild-RoPE-store launch (no `output`
+    round trip); get_value_cache is one landing + PCIe-fetch launch.  No kernel spins on another.
   * the host V stride passed to the mover is the tensor's real stride (max_length // C chunks); the
     reference passes the prompt length (kv_cache.py:1090), identical whenever prompt == max_length.
   * top-k membership under exact bf16 ties is defined (lowest landmark slot); torch.topk's is not.
@@ -85,6 +86,10 @@ class ShadowKVCache_CPU:
         self.temp = torch.zeros(1, device=self.device, dtype=dtype)
         self.output = torch.zeros(1, device=self.device, dtype=dtype)
         self._select_ws = None
+        # staging buffers of the two-phase (spin-free) chunk movement: moved hit chunks of one layer
+        self._temp_k = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
+        self._temp_v = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
+        self._staged_layer = -1
         self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -245,27 +250,37 @@ class ShadowKVCache_CPU:
                                       ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
                                       self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
               "get_retrieval_position_ids")
+        self._stage_hits(layer_idx)
         return self.position_ids[layer_idx]
 
+    def _stage_hits(self, layer_idx):
+        """Phase 1 of the chunk movement for BOTH buffers of a layer, once per (layer, selection): every hit
+        chunk whose slot changes is copied to the staging buffers.  Must run on the stream that produced
+        offsets / cnts, before the side stream forks (the fork then orders it before both landings)."""
+        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        check(lib().skv_stage_hit_chunks(ptr(kbuf), ptr(self._temp_k), ptr(vbuf), ptr(self._temp_v),
+                                         ptr(self.offsets), ptr(self.cnts), kbuf.stride(1),
+                                         self.sparse_start * self.head_dim, self.block_num, self.select_sets,
+                                         current_stream_handle()), "stage_hit_chunks")
+
     def get_value_cache(self, layer_idx, position_ids):
-        """Hit chunks compacted in place, miss chunks fetched from pinned host memory into the sparse
-        region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream)."""
+        """Hit chunks moved to their new slots, miss chunks fetched from pinned host memory into the sparse
+        region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream): lands the
+        hit chunks staged by get_retrieval_position_ids and pulls the misses over PCIe with plain 16-B loads
+        (49-56 GB/s measured, the DMA ceiling; tools/pcie_probe.hip)."""
         vhost = self.v_cache_cpu[layer_idx]
         vbuf = self.v_cache_buffer[layer_idx]
-        check(lib().skv_move_chunks(ptr(vhost), ptr(vbuf), ptr(self.offsets), ptr(self.cnts), ptr(self.signals),
+        check(lib().skv_land_chunks(ptr(vhost), ptr(vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
                                     vhost.stride(1), vbuf.stride(1), self.sparse_start * self.head_dim,
                                     self.block_num, self.select_sets, current_stream_handle()), "get_value_cache")
         return vbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
     def get_key_cache(self, layer_idx, position_ids, rope_func, cos_sin_cache):
-        """Hit chunks compacted in place, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
-        region (kv_cache.py:1108-1176).  `rope_func` is unused, as in the reference."""
+        """Hit chunks moved to their new slots, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
+        region (kv_cache.py:1108-1176), one launch.  `rope_func` is unused, as in the reference."""
         kbuf = self.k_cache_buffer[layer_idx]
-        check(lib().skv_move_chunks(0, ptr(kbuf), ptr(self.offsets), ptr(self.cnts), ptr(self._signals_k), 0,
-                                    kbuf.stride(1), self.sparse_start * self.head_dim, self.block_num,
-                                    self.select_sets, current_stream_handle()), "get_key_cache/compaction")
         tensor_op.rebuild_keys(self.U[layer_idx], self.SV[layer_idx], cos_sin_cache, position_ids, self.cnts, kbuf,
-                               self.sparse_start, self.chunk_size)
+                               self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
     def note_kv_appended(self, incoming=1):

@@ -134,7 +134,8 @@ def batch_gather_gemm_rotary_pos_emb_cuda(a, b, cos_sin, position_ids, output, c
                                                 cnts)
 
 
-def rebuild_keys(U, SV, cos_sin, position_ids, cnts, cache, sparse_start, chunk_size):
+def rebuild_keys(U, SV, cos_sin, position_ids, cnts, cache, sparse_start, chunk_size, hit_temp=None,
+                 hit_offsets=None):
     """Fused K rebuild: cache[b,h,sparse_start+i] = RoPE(bf16(U[b,pos(i)].SV[b,h]^T)) for chunks >= cnts.
     U [bs, seq, r], SV [bs, heads, 128, r], position_ids int64 [bs, heads, S], cache [bs, heads, rows, 128]."""
     bs, seq_len, rank = U.shape
@@ -145,7 +146,8 @@ def rebuild_keys(U, SV, cos_sin, position_ids, cnts, cache, sparse_start, chunk_
     check(lib().skv_rebuild_keys(ptr(U), ptr(SV), ptr(cos_sin), ptr(position_ids), ptr(cnts), ptr(cache), bs, heads,
                                  seq_len, head_dim, rank, position_ids.shape[-1], int(chunk_size), cos_sin.stride(0),
                                  cache.stride(0), cache.stride(1), cache.stride(2), int(sparse_start),
-                                 1 if width == 128 else 2, current_stream_handle()), "rebuild_keys")
+                                 1 if width == 128 else 2, ptr(hit_temp), ptr(hit_offsets), current_stream_handle()),
+          "rebuild_keys")
     return cache
 
 

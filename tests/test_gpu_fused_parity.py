@@ -108,7 +108,7 @@ def test_rebuild_keys(glm):
     Ud, SVd, csd, idd, cnd = U.to(DEV), SV.to(DEV), cs.to(DEV), ids.to(DEV), cnts.to(DEV)
     rc = L_.lib().skv_rebuild_keys(Ud.data_ptr(), SVd.data_ptr(), csd.data_ptr(), idd.data_ptr(), cnd.data_ptr(),
                                    c1.data_ptr(), bs, heads, L, 128, R, S, C, cs.stride(0), c1.stride(0),
-                                   c1.stride(1), c1.stride(2), start, 2 if glm else 1, _stream())
+                                   c1.stride(1), c1.stride(2), start, 2 if glm else 1, 0, 0, _stream())
     L_.check(rc, "skv_rebuild_keys")
     torch.cuda.synchronize()
     c1 = c1.cpu()
