@@ -199,7 +199,7 @@ class DecoderLM:
         for l, layer in enumerate(self.layers):
             residual, hs = tensor_op.add_rmsnorm(x, residual, layer.input_layernorm_weight,
                                                  layer.input_layernorm_variance_epsilon)
-            qkv = F.linear(hs, layer.wqkv, layer.bqkv)
+            qkv = tensor_op.linear_decode(hs, layer.wqkv, layer.bqkv)
             q = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l],
                                           c.v_cache_buffer[l], self.num_heads, self.num_key_value_heads,
                                           q_override=None if q_table is None else q_table[l])
@@ -211,12 +211,13 @@ class DecoderLM:
             cur.wait_stream(side)
             attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,
                                                      kv_len_dev=kv_len_dev)
-            o = F.linear(attn.reshape(bs, 1, self.hidden_size), layer.wo)
+            o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
             residual, hs = tensor_op.add_rmsnorm(o, residual, layer.post_attention_layernorm_weight,
                                                  layer.post_attention_layernorm_variance_epsilon)
-            x = F.linear(tensor_op.silu_and_mul_fused(F.linear(hs, layer.gate_up_proj)), layer.down_proj)
+            x = tensor_op.linear_decode(tensor_op.linear_decode(hs, layer.gate_up_proj, fuse_silu_mul=True),
+                                        layer.down_proj)
         _, hs = tensor_op.add_rmsnorm(x, residual, self.norm_weight, self.norm_variance_epsilon)
-        return F.linear(hs, self.lm_head).float()
+        return tensor_op.linear_decode(hs, self.lm_head).float()
 
     def get_ctx(self, input_ids):
         past = self.kv_cache.get_kv_len()

@@ -35,6 +35,20 @@ def silu_and_mul(out, x):
     return out
 
 
+def linear_decode(x, w, bias=None, fuse_silu_mul=False):
+    """F.linear for one token (x [1, 1, K] or [1, K]) on the native GEMV; falls back to F.linear for bs > 1 or
+    shapes the kernel is not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
+    K = x.shape[-1]
+    if x.numel() != K or K % 512 or not x.is_contiguous() or not w.is_contiguous():
+        out = F.linear(x, w, bias)
+        return silu_and_mul_fused(out) if fuse_silu_mul else out
+    N = w.shape[0]
+    y = torch.empty(x.shape[:-1] + ((N // 2) if fuse_silu_mul else N,), dtype=x.dtype, device=x.device)
+    check(lib().skv_gemv_bf16(ptr(w), ptr(x), ptr(bias), ptr(y), N, K, 1 if fuse_silu_mul else 0,
+                              current_stream_handle()), "gemv")
+    return y
+
+
 def add_rmsnorm(x, residual, w, eps):
     """(h, y): h = x + residual (bf16; residual None -> h = x), y = RMSNorm(h) * w.  One native launch."""
     shape = x.shape

@@ -64,10 +64,10 @@ def test_fused_step_close_to_reference_call_order():
     c2.note_kv_appended(1)
     torch.cuda.synchronize()
     assert c1.kv_offset == c2.kv_offset and c1.gen_offset == c2.gen_offset
-    assert torch.equal(c1.position_ids[0], c2.position_ids[0])
-    # new K/V rows of layer 0 (RoPE'd k, raw v) must be bit-identical: same qkv GEMV, same rotation arithmetic
-    assert torch.equal(c1.k_cache_buffer[0][:, :, row].view(torch.int16), c2.k_cache_buffer[0][:, :, row].view(torch.int16))
-    assert torch.equal(c1.v_cache_buffer[0][:, :, row].view(torch.int16), c2.v_cache_buffer[0][:, :, row].view(torch.int16))
+    # new K/V rows of layer 0 (RoPE'd k, raw v): same rotation arithmetic, the QKV projection differs only in
+    # f32 accumulation order (native GEMV vs hipBLASLt)
+    assert torch.allclose(c1.k_cache_buffer[0][:, :, row].float(), c2.k_cache_buffer[0][:, :, row].float(), rtol=0.02, atol=0.02)
+    assert torch.allclose(c1.v_cache_buffer[0][:, :, row].float(), c2.v_cache_buffer[0][:, :, row].float(), rtol=0.02, atol=0.02)
     rel = (la - lb).abs().max() / la.abs().max()
     assert float(rel) < 0.05, float(rel)
 
@@ -91,3 +91,22 @@ def test_fused_small_ops_against_torch():
     out = tensor_op.silu_and_mul_fused(gu)
     ref = torch.nn.functional.silu(gu[..., :14336].float()).bfloat16().float() * gu[..., 14336:].float()
     assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,K,silu", [(6144, 4096, False), (4096, 14336, False), (28672, 4096, True), (1000, 1024, False),
+                                      (4101, 512, False)])
+def test_gemv_against_f32_reference(N, K, silu):
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    x = torch.randn(1, 1, K, device=DEV, generator=g).bfloat16()
+    bias = None if silu else (torch.randn(N, device=DEV, generator=g) * 0.1).bfloat16()
+    y = tensor_op.linear_decode(x, w, bias, fuse_silu_mul=silu)
+    ref = w.float() @ x.view(K).float()
+    if silu:
+        gte, up = ref[: N // 2].bfloat16().float(), ref[N // 2:].bfloat16().float()
+        ref = torch.nn.functional.silu(gte).bfloat16().float() * up
+    else:
+        ref = ref.bfloat16().float() + bias.float()
+    assert y.shape[-1] == ref.numel()
+    assert torch.allclose(y.view(-1).float(), ref, rtol=2 ** -6, atol=2e-2), float((y.view(-1).float() - ref).abs().max())
