@@ -235,6 +235,12 @@ SKV_EXPORT int skv_silu_and_mul(const void* x, void* out, int rows, int inter, s
 SKV_EXPORT int skv_gemv_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                   skv_stream_t stream);
 
+/* Same with "residual add + RMSNorm" fused in front (K must be 4096): h = x + residual (residual nullable),
+ * xn = RMSNorm(h) * norm_weight, y = W . xn (+bias / fused SiLU*mul); h is stored to h_out when non-NULL
+ * (the new residual stream).  One launch for tensor_op.layer_norm + F.linear of llama.py:354-380, :410-415. */
+SKV_EXPORT int skv_norm_gemv_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                       void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul, skv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

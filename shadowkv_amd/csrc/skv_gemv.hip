@@ -14,12 +14,19 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int R, bool SILU_PAIR>
+// NORM variant (K == 4096): x is the pre-norm hidden state; every wave recomputes h = x + residual (bf16),
+// the RMS statistics (its 64 lanes x 8 k-steps cover all 4096 elements) and xn = bf16(h * rstd * w_norm) in
+// registers, so "residual add + RMSNorm + projection" is one launch; block 0 / wave 0 stores h (the new
+// residual stream).  Same rounding points as the separate skv_add_rmsnorm launch.
+template <int R, bool SILU_PAIR, bool NORM>
 __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N,
-                                                       int K, int I /* SILU_PAIR: rows of one half */) {
+                                                       int K, int I /* SILU_PAIR: rows of one half */,
+                                                       const bf16_t* __restrict__ residual,
+                                                       const bf16_t* __restrict__ w_norm, bf16_t* __restrict__ h_out,
+                                                       float eps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ksteps = K / 512;  // 64 lanes x 8 elements per step
+    const int ksteps = NORM ? 8 : K / 512;  // 64 lanes x 8 elements per step (NORM: K == 4096, static trip count)
     // rows of this wave
     int rows[R];
     const int unit0 = (blockIdx.x * 4 + wave) * (SILU_PAIR ? R / 2 : R);
@@ -39,21 +46,66 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
         wp[r] = W + (size_t)row * K + 8 * lane;
     }
     const bf16_t* xp = x + 8 * lane;
+    // the first weight segments do not depend on the norm prologue: get them in flight before it
+    u32x4 wpre[NORM ? R : 1][4];
+    if (NORM) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                wpre[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)u * 512));
+    }
+    f32x2 xn[NORM ? 8 : 1][4];
+    if (NORM) {
+        u32x4 hx[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u32x4 a = *reinterpret_cast<const u32x4*>(xp + (size_t)u * 512);
+            if (residual) {
+                u32x4 c = *reinterpret_cast<const u32x4*>(residual + 8 * lane + (size_t)u * 512);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = pack_bf2(bf_lo(a[j]) + bf_lo(c[j]), bf_hi(a[j]) + bf_hi(c[j]));
+            }
+            hx[u] = a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ss = __builtin_fmaf(bf_lo(a[j]), bf_lo(a[j]), ss);
+                ss = __builtin_fmaf(bf_hi(a[j]), bf_hi(a[j]), ss);
+            }
+        }
+        if (h_out && blockIdx.x == 0 && wave == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(h_out + 8 * lane + (size_t)u * 512) = hx[u];
+        }
+        ss = wave_tree_sum(ss);
+        const float rstd = 1.0f / sqrtf(ss / (float)K + eps);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u32x4 g = *reinterpret_cast<const u32x4*>(w_norm + 8 * lane + (size_t)u * 512);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xn[u][j] = (f32x2){bfr(bf_lo(hx[u][j]) * rstd * bf_lo(g[j])), bfr(bf_hi(hx[u][j]) * rstd * bf_hi(g[j]))};
+        }
+    }
     f32x2 acc[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[r][j] = (f32x2){0.f, 0.f};
 
+#pragma unroll 2
     for (int ks = 0; ks < ksteps; ks += 4) {
         u32x4 wv[R][4], xv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (ks + u < ksteps) {
-                xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(ks + u) * 512);
+                if (!NORM) xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(ks + u) * 512);
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)(ks + u) * 512));
+                for (int r = 0; r < R; ++r) {
+                    if (NORM && ks == 0) wv[r][u] = wpre[r][u];
+                    else wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)(ks + u) * 512));
+                }
             }
         }
 #pragma unroll
@@ -61,7 +113,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
             if (ks + u < ksteps) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x2 xx = (f32x2){bf_lo(xv[u][j]), bf_hi(xv[u][j])};
+                    const f32x2 xx = NORM ? xn[(ks + u) & 7][j] : (f32x2){bf_lo(xv[u][j]), bf_hi(xv[u][j])};
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const f32x2 ww = (f32x2){bf_lo(wv[r][u][j]), bf_hi(wv[r][u][j])};
@@ -98,21 +150,35 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     }
 }
 
-extern "C" int skv_gemv_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
-                             skv_stream_t stream) {
+static int launch_gemv(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
+                       const void* residual, const void* w_norm, void* h_out, float eps, bool norm, hipStream_t st) {
     if (!W || !x || !y || N < 1) return SKV_ERR_ARG;
     if (K % 512 || K < 512) return SKV_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
+    if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
+#define SKV_GEMV(SILU, NORMF, GRID, IARG)                                                                            \
+    hipLaunchKernelGGL((skv_gemv_kernel<4, SILU, NORMF>), dim3(GRID), dim3(256), 0, st, (const bf16_t*)W,             \
+                       (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, IARG, (const bf16_t*)residual,        \
+                       (const bf16_t*)w_norm, (bf16_t*)h_out, eps)
     if (fuse_silu_mul) {
         if (N % 2 || bias) return SKV_ERR_ARG;
         const int I = N / 2;
         const int grid = (I + 4 * 2 - 1) / (4 * 2);  // 4 waves x 2 (gate, up) pairs
-        hipLaunchKernelGGL((skv_gemv_kernel<4, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)W, (const bf16_t*)x,
-                           (const bf16_t*)nullptr, (bf16_t*)y, N, K, I);
+        if (norm) SKV_GEMV(true, true, grid, I); else SKV_GEMV(true, false, grid, I);
     } else {
         const int grid = (N + 4 * 4 - 1) / (4 * 4);
-        hipLaunchKernelGGL((skv_gemv_kernel<4, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)W, (const bf16_t*)x,
-                           (const bf16_t*)bias, (bf16_t*)y, N, K, 0);
+        if (norm) SKV_GEMV(false, true, grid, 0); else SKV_GEMV(false, false, grid, 0);
     }
+#undef SKV_GEMV
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+}
+
+extern "C" int skv_gemv_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
+                             skv_stream_t stream) {
+    return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, nullptr, nullptr, nullptr, 0.f, false, (hipStream_t)stream);
+}
+
+extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                                  void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul,
+                                  skv_stream_t stream) {
+    return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, residual, norm_weight, h_out, eps, true, (hipStream_t)stream);
 }

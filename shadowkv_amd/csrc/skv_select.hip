@@ -212,6 +212,18 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
 // ---------------------------------------------------------------------------------------
 #define SKV_SEL_THREADS 1024
 
+// Phase stamps for tools/topk_probe.hip (diagnostic build only, -DSKV_TOPK_STAMPS; no stamp executes in the
+// shipped library).  100 MHz wall clock, written by thread 0 of workgroup 0 to a buffer nothing else reads.
+#ifdef SKV_TOPK_STAMPS
+__device__ unsigned long long g_topk_stamps[24];
+#define TOPK_STAMP(i)                                                                 \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64();   \
+    } while (0)
+#else
+#define TOPK_STAMP(i)
+#endif
+
 // inclusive scan of two ints per thread over the 1024-thread workgroup (same barriers for both)
 __device__ __forceinline__ void block_scan_incl2(int& a, int& b, int* s_wave /*[32]*/, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -272,23 +284,25 @@ __device__ __forceinline__ void select_bin_desc_wave0(const int* hist, int k, in
     }
 }
 
-// hist[bin] += 1 for every lane with `valid`, wave-aggregated: softmax scores of a long context are
-// nearly uniform, so most lanes hit the SAME bin and plain LDS atomics would serialise 64-way.  Two
-// rounds peel off the two most common bins of the wave with one atomic each, the rest add singly.
-__device__ __forceinline__ void hist_add_aggregated(int* hist, int bin, bool valid, int lane) {
+// hist[bin] += w for every active lane, wave-aggregated: softmax scores of a long context are nearly
+// uniform, so most lanes hit the SAME bin and plain LDS atomics would serialise 64-way.  Two rounds peel
+// off the two most common bins of the wave with one atomic each, the rest add singly.  Must be called
+// by a subset of lanes under ordinary divergence (uses the exec mask).
+__device__ __forceinline__ void hist_add_aggregated_w(int* hist, int bin, int w, int lane) {
+    bool pending = true;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
-        if (valid) {
+        if (pending) {
             const int b0 = __builtin_amdgcn_readfirstlane(bin);
             const bool same = bin == b0;
             const unsigned long long m = __ballot(same);
             if (same) {
-                if (lane == __ffsll((long long)m) - 1) atomicAdd(&hist[b0], __popcll(m));
-                valid = false;
+                if (lane == __ffsll((long long)m) - 1) atomicAdd(&hist[b0], w * __popcll(m));
+                pending = false;
             }
         }
     }
-    if (valid) atomicAdd(&hist[bin], 1);
+    if (pending) atomicAdd(&hist[bin], w);
 }
 
 template <bool STAGE_LDS>
@@ -319,38 +333,54 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         const u32x4* gvec = reinterpret_cast<const u32x4*>(gsc);
         const u32x4* svec = STAGE_LDS ? reinterpret_cast<const u32x4*>(s_score) : gvec;
         const int nvec = score_stride / 8;
+        TOPK_STAMP(0);
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
-        // ---- pass 1: histogram of the high byte, fused with the staging copy
+        // ---- pass 1: histogram of the high byte, fused with the staging copy.  The 8 scores of a vector
+        // almost always share their high byte (neighbouring landmarks, similar magnitude): one weighted,
+        // wave-aggregated add per vector; vectors with mixed high bytes fall back to per-element adds.
         for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
             const u32x4 v = gvec[i];
             if (STAGE_LDS) reinterpret_cast<u32x4*>(s_score)[i] = v;
+            const int b0 = (int)((v[0] >> 8) & 0xff);
+            bool uniform = i * 8 + 7 < N;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
-                hist_add_aggregated(s_hist, val >> 8, i * 8 + e < N, lane);
+            for (int j = 0; j < 4; ++j)
+                uniform = uniform && (int)((v[j] >> 8) & 0xff) == b0 && (int)(v[j] >> 24) == b0;
+            if (uniform) {
+                hist_add_aggregated_w(s_hist, b0, 8, lane);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                    if (i * 8 + e < N) atomicAdd(&s_hist[val >> 8], 1);
+                }
             }
         }
         __syncthreads();
+        TOPK_STAMP(1);
         if (wave == 0) select_bin_desc_wave0(s_hist, S, s_out, lane);
         __syncthreads();
         const int hi = s_out[0], above_hi = s_out[1];
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
-        // ---- pass 2: histogram of the low byte inside that bin
+        TOPK_STAMP(2);
+        // ---- pass 2: histogram of the low byte inside that bin (values spread over many bins: plain atomics)
         for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
             const u32x4 v = svec[i];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
-                hist_add_aggregated(s_hist, val & 0xff, (i * 8 + e < N) && ((val >> 8) == hi), lane);
+                if ((i * 8 + e < N) && ((val >> 8) == hi)) atomicAdd(&s_hist[val & 0xff], 1);
             }
         }
         __syncthreads();
+        TOPK_STAMP(3);
         if (wave == 0) select_bin_desc_wave0(s_hist, S - above_hi, s_out + 2, lane);
         __syncthreads();
         const int thr = (hi << 8) | s_out[2];
         const int need_eq = S - (above_hi + s_out[3]);
+        TOPK_STAMP(4);
         // ---- pass 3: ordered compaction; thread owns `segv` consecutive 8-element vectors
         const int segv = (nvec + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
         const int v0 = min(tid * segv, nvec), v1 = min(v0 + segv, nvec);
@@ -365,8 +395,10 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
                 c_eq += in && val == thr;
             }
         }
+        TOPK_STAMP(5);
         int gt_before = c_gt, eq_before = c_eq;
         block_scan_incl2(gt_before, eq_before, s_wave, tid);
+        TOPK_STAMP(6);
         gt_before -= c_gt;
         eq_before -= c_eq;
         for (int i = v0; i < v1; ++i) {
@@ -395,6 +427,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         if (tid < S) s_cur[tid] = (int)cur_in[(size_t)b * S + tid];
     }
 
+    TOPK_STAMP(7);
     // ---- hash set of resident ids: key -> lowest slot
     for (int i = tid; i < H; i += SKV_SEL_THREADS) {
         s_hkeys[i] = -1;
@@ -420,6 +453,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         }
     }
     __syncthreads();
+    TOPK_STAMP(8);
     // ---- classify the new ids
     int my_key = -1, my_slot = -1;
     if (tid < S) {
@@ -439,6 +473,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         if (my_slot >= 0) s_byslot[my_slot] = my_key;
     }
     __syncthreads();
+    TOPK_STAMP(9);
     // hits ordered by old slot (compaction of s_byslot), misses in selection order
     const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
     const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
@@ -451,8 +486,12 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     if (is_miss) s_miss[miss_incl - 1] = my_key;
     __syncthreads();
     const int cnt = s_out[4], nm = s_out[5];
-    // rank sort of the misses by chunk id (ties by position): P threads share one element
-    {
+    TOPK_STAMP(10);
+    // misses ordered by chunk id.  They are collected in selection order (ascending landmark slot) and the
+    // slot -> chunk-id map is normally increasing, so they are usually sorted already: one vote decides; the
+    // rank sort (ties by position, P threads share one element) only runs otherwise.
+    const int unsorted_here = (tid > 0 && tid < nm && s_miss[tid - 1] > s_miss[tid]) ? 1 : 0;
+    if (__syncthreads_or(unsorted_here)) {
         const int P = SKV_SEL_THREADS / SP;
         const int i = tid / P, part = tid % P;
         if (i < nm) {
@@ -464,8 +503,11 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
             }
             if (r) atomicAdd(&s_rank[i], r);
         }
+    } else if (tid < nm) {
+        s_rank[tid] = tid;
     }
     __syncthreads();
+    TOPK_STAMP(11);
     // ---- write out
     if (is_hit_slot) {
         int o = hit_incl - 1;
@@ -478,6 +520,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         offsets[(size_t)b * S + o] = key;
     }
     if (tid == 0) cnts[b] = cnt;
+    TOPK_STAMP(12);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -184,11 +184,12 @@ class DecoderLM:
     @torch.inference_mode()
     def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
         """Same computation as inference() for q_len == 1, with the small ops fused and the step's
-        scalars in device memory (graph-capturable): 16 launches per layer instead of ~40.
+        scalars in device memory (graph-capturable): 13 launches per layer instead of ~40.
           token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
           kv_len / kv_len_dev: rows attended (= row_idx + 1), q_table: optional [L, bs, Hq, 1, D] synthetic queries.
-        Per layer: add+RMSNorm -> QKV GEMV -> split/RoPE/cache-push -> select -> [side stream: V move] ||
-        K move + rebuild -> attention -> O GEMV -> add+RMSNorm -> gate/up GEMV -> SiLU*mul -> down GEMV."""
+        Per layer: [add+RMSNorm+QKV GEMV] -> split/RoPE/cache-push -> select (3) -> stage hits -> [side stream:
+        land V + PCIe fetch] || [land K + rebuild] -> attention (2) -> O GEMV -> [add+RMSNorm+gate/up GEMV+SiLU*mul]
+        -> down GEMV."""
         c = self.kv_cache
         x = F.embedding(token, self.embed_tokens)
         residual = None
@@ -197,9 +198,8 @@ class DecoderLM:
         bs = x.shape[0]
         c.incoming_q_len = 1
         for l, layer in enumerate(self.layers):
-            residual, hs = tensor_op.add_rmsnorm(x, residual, layer.input_layernorm_weight,
-                                                 layer.input_layernorm_variance_epsilon)
-            qkv = tensor_op.linear_decode(hs, layer.wqkv, layer.bqkv)
+            residual, qkv = tensor_op.norm_linear_decode(x, residual, layer.input_layernorm_weight,
+                                                          layer.input_layernorm_variance_epsilon, layer.wqkv, layer.bqkv)
             q = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l],
                                           c.v_cache_buffer[l], self.num_heads, self.num_key_value_heads,
                                           q_override=None if q_table is None else q_table[l])
@@ -212,12 +212,12 @@ class DecoderLM:
             attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,
                                                      kv_len_dev=kv_len_dev)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
-            residual, hs = tensor_op.add_rmsnorm(o, residual, layer.post_attention_layernorm_weight,
-                                                 layer.post_attention_layernorm_variance_epsilon)
-            x = tensor_op.linear_decode(tensor_op.linear_decode(hs, layer.gate_up_proj, fuse_silu_mul=True),
-                                        layer.down_proj)
-        _, hs = tensor_op.add_rmsnorm(x, residual, self.norm_weight, self.norm_variance_epsilon)
-        return tensor_op.linear_decode(hs, self.lm_head).float()
+            residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
+                                                          layer.post_attention_layernorm_variance_epsilon,
+                                                          layer.gate_up_proj, fuse_silu_mul=True)
+            x = tensor_op.linear_decode(act, layer.down_proj)
+        _, logits = tensor_op.norm_linear_decode(x, residual, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
+        return logits.float()
 
     def get_ctx(self, input_ids):
         past = self.kv_cache.get_kv_len()

@@ -49,6 +49,22 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False):
     return y
 
 
+def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False):
+    """(h, y): h = x + residual (residual None -> h = x), y = linear(RMSNorm(h) * norm_w) for one token, one
+    native launch when the hidden size is 4096; otherwise add_rmsnorm + linear_decode."""
+    K = x.shape[-1]
+    if x.numel() != K or K != 4096 or not x.is_contiguous() or not w.is_contiguous():
+        h, hs = add_rmsnorm(x, residual, norm_w, eps)
+        return h, linear_decode(hs, w, bias, fuse_silu_mul)
+    N = w.shape[0]
+    y = torch.empty(x.shape[:-1] + ((N // 2) if fuse_silu_mul else N,), dtype=x.dtype, device=x.device)
+    h = torch.empty_like(x) if residual is not None else x
+    check(lib().skv_norm_gemv_bf16(ptr(w), ptr(x), ptr(residual), ptr(norm_w), float(eps),
+                                   ptr(h) if residual is not None else 0, ptr(bias), ptr(y), N, K,
+                                   1 if fuse_silu_mul else 0, current_stream_handle()), "norm_gemv")
+    return h, y
+
+
 def add_rmsnorm(x, residual, w, eps):
     """(h, y): h = x + residual (bf16; residual None -> h = x), y = RMSNorm(h) * w.  One native launch."""
     shape = x.shape

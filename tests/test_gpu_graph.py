@@ -110,3 +110,19 @@ def test_gemv_against_f32_reference(N, K, silu):
         ref = ref.bfloat16().float() + bias.float()
     assert y.shape[-1] == ref.numel()
     assert torch.allclose(y.view(-1).float(), ref, rtol=2 ** -6, atol=2e-2), float((y.view(-1).float() - ref).abs().max())
+
+
+def test_norm_gemv_equals_separate_launches():
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    r = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(4096, device=DEV, generator=g)).bfloat16()
+    for N, silu in ((6144, False), (28672, True)):
+        w = (torch.randn(N, 4096, device=DEV, generator=g) * 0.05).bfloat16()
+        h1, y1 = tensor_op.norm_linear_decode(x, r, nw, 1e-5, w, fuse_silu_mul=silu)
+        h2, hs = tensor_op.add_rmsnorm(x, r, nw, 1e-5)
+        y2 = tensor_op.linear_decode(hs, w, fuse_silu_mul=silu)
+        assert torch.equal(h1.view(torch.int16), h2.view(torch.int16))
+        # the RMS sum is reduced in a different order (one wave vs four): rstd may differ in its last bit
+        assert torch.allclose(y1.float(), y2.float(), rtol=2 ** -6, atol=2e-2)

@@ -1,0 +1,31 @@
+// Diagnostic build of the top-k + diff kernel with phase stamps (see TOPK_STAMP in skv_select.hip).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSKV_TOPK_STAMPS -I shadowkv_amd/csrc tools/topk_probe.hip -o /tmp/topk_probe
+#include "../shadowkv_amd/csrc/skv_select.hip"
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+int main() {
+    const int B = 8, N = 15560, S = 256, stride = (N + 7) & ~7;
+    std::vector<uint16_t> sc((size_t)B * stride);
+    std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * S);
+    srand(3);
+    for (auto& v : sc) { float p = 6.4e-5f * (0.6f + 0.8f * rand() / RAND_MAX); uint32_t u; memcpy(&u, &p, 4); v = u >> 16; }
+    for (int b = 0; b < B; ++b) for (int j = 0; j < N; ++j) lm[(size_t)b * N + j] = j + j / 300;
+    for (int b = 0; b < B; ++b) for (int j = 0; j < S; ++j) cached[(size_t)b * S + j] = (j * 61) % N;
+    uint16_t* dsc; int64_t *dlm, *dc, *dsel; int32_t *doff, *dcnt;
+    hipMalloc(&dsc, sc.size() * 2); hipMalloc(&dlm, lm.size() * 8); hipMalloc(&dc, cached.size() * 8); hipMalloc(&dsel, cached.size() * 8);
+    hipMalloc(&doff, B * S * 4); hipMalloc(&dcnt, B * 4);
+    hipMemcpy(dsc, sc.data(), sc.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dlm, lm.data(), lm.size() * 8, hipMemcpyHostToDevice);
+    for (int it = 0; it < 3; ++it) {
+        hipMemcpy(dc, cached.data(), cached.size() * 8, hipMemcpyHostToDevice);
+        int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, B, N, S, 0);
+        hipDeviceSynchronize();
+        unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
+        const char* names[] = {"stage+hist1", "select1", "zero", "hist2", "select2", "count", "scan", "assign+gather", "hash init+insert", "lookup", "scan2", "ranksort", "write"};
+        printf("run %d rc=%d total %.2f us :", it, rc, (st[12] - st[0]) / 100.0);
+        for (int i = 0; i < 12; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
+        printf("\n");
+    }
+    return 0;
+}
