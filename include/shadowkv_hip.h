@@ -195,6 +195,17 @@ SKV_EXPORT int skv_land_chunks(const void* host_values, void* cache_buffer, cons
                     const int32_t* cnts, long long host_block_stride, long long cache_block_stride,
                     long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream);
 
+/* get_key_cache and get_value_cache of one layer as ONE launch (after skv_stage_hit_chunks): K chunks >= cnts are
+ * rebuilt (as skv_rebuild_keys), moved K hits land from k_temp, and the V chunks land from v_temp / the pinned host
+ * table (as skv_land_chunks) in extra workgroups of the same grid - no stream fork/join between the two halves.
+ * K and V caches must share strides. */
+SKV_EXPORT int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
+                 const int32_t* offsets, void* k_cache, const void* k_temp, const void* v_host, void* v_cache,
+                 const void* v_temp, int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets,
+                 int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                 long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                 skv_stream_t stream);
+
 /* Sparse decode attention (replaces flash_attn_with_kvcache at /root/reference/models/base.py:341 for
  * q_len == 1).  q [bs][q_heads][128], k/v [bs][kv_heads][rows][128] (kv_head_stride elements between heads),
  * out [bs][q_heads][128] bf16.  kv_len_dev (int32 on device) overrides kv_len when non-NULL.

@@ -41,6 +41,7 @@ _SIGS = {
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
     "skv_move_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
+    "skv_fetch_kv": (c_int, [c_p] * 11 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
     "skv_stage_hit_chunks": (c_int, [c_p] * 6 + [c_ll] * 2 + [c_int] * 2 + [c_p]),
     "skv_land_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_attn_workspace_bytes": (c_sz, [c_int] * 3),

@@ -25,7 +25,8 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
-                       hipStream_t st);
+                       const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
+                       long long v_stride, long long v_off, hipStream_t st);
 int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
                           const int32_t* cnts, long long stride_elems, long long off_elems, int B, int S,
                           hipStream_t st);
@@ -149,7 +150,7 @@ int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const v
                                      seq_len, embed_dim, rank, sparse_budget / chunk_size, chunk_size, 0,
                                      (long long)heads * sparse_budget * embed_dim,
                                      (long long)sparse_budget * embed_dim, embed_dim, 0, 0, nullptr, nullptr,
-                                     (hipStream_t)stream));
+                                     nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
 }
 
 #define SKV_ROPE_PUSH_ARGS                                                                                       \
@@ -274,6 +275,22 @@ int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const i
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len,
                                      head_dim, rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b,
                                      cache_stride_h, cache_stride_s, sparse_start, rope_mode, hit_temp, hit_offsets,
+                                     nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
+}
+
+int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
+                 const int32_t* offsets, void* k_cache, const void* k_temp, const void* v_host, void* v_cache,
+                 const void* v_temp, int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets,
+                 int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                 long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                 skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !chunk_ids || !cnts || !offsets || !k_cache || !k_temp || !v_host || !v_cache || !v_temp)
+        return SKV_ERR_ARG;
+    if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
+    return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, k_temp, offsets, v_host, v_cache, v_temp,
+                                     host_block_stride, cache_stride_h, (long long)sparse_start * head_dim,
                                      (hipStream_t)stream));
 }
 

@@ -46,7 +46,43 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     int heads, int seq_len, int S, int C, int ids64, long long cs_stride,
     long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0,
     const bf16_t* __restrict__ hit_temp, // nullable: [bs*heads][S][C*128] moved hit chunks staged by skv_stage_hits
-    const int32_t* __restrict__ hit_offsets /* [bs*heads][S] */) {
+    const int32_t* __restrict__ hit_offsets /* [bs*heads][S] */,
+    // optional second role (blocks blockIdx.x >= rebuild_tiles): land the V chunks of this (batch, head) -
+    // moved hits from v_temp, misses from the pinned host table - so "K rebuild || V fetch" is ONE launch with no
+    // stream fork/join around it.  Rebuild tiles come first in dispatch order (short, few), landing blocks fill
+    // the remaining CUs and are PCIe-bound.
+    int rebuild_tiles, const u32x4* __restrict__ v_host, u32x4* __restrict__ v_buf, const u32x4* __restrict__ v_temp,
+    long long v_host_stride_u128, long long v_stride_u128, long long v_off_u128) {
+    if ((int)blockIdx.x >= rebuild_tiles) {
+        const int bh2 = blockIdx.y, tid2 = threadIdx.x, unit = tid2 & 127, rsub = tid2 >> 7;
+        const int cnt2 = cnts ? cnts[bh2] : 0;
+        const int blk = blockIdx.x - rebuild_tiles;
+        u32x4 lv[4];
+        bool lact[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = blk * 8 + k * 2 + rsub;
+            lact[k] = false;
+            if (i < S) {
+                const int off = hit_offsets[(size_t)bh2 * S + i];
+                if (i < cnt2) {
+                    if (off != i) {
+                        lact[k] = true;
+                        lv[k] = v_temp[((long long)bh2 * S + i) * 128 + unit];
+                    }
+                } else {
+                    lact[k] = true;
+                    lv[k] = v_host[(long long)bh2 * v_host_stride_u128 + (long long)off * 128 + unit];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = blk * 8 + k * 2 + rsub;
+            if (lact[k]) v_buf[(long long)bh2 * v_stride_u128 + v_off_u128 + (long long)i * 128 + unit] = lv[k];
+        }
+        return;
+    }
     constexpr int R = KS * 32;
     constexpr int UNITS_PER_ROW = R / 8;                       // 16-B units per SV row
     constexpr int SV_ITERS = (RB_D * UNITS_PER_ROW + 255) / 256;
@@ -209,7 +245,8 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
-                       hipStream_t st) {
+                       const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
+                       long long v_stride, long long v_off, hipStream_t st) {
     if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
     if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
     if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
@@ -219,11 +256,17 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
     if (hit_temp && (C != 8 || out_stride_s != 128 || !hit_offsets)) return SKV_ERR_UNSUPPORTED;
     const int tiles = (S * C + RB_ROWS - 1) / RB_ROWS;
     const size_t smem = RB_D * RB_SV_PITCH + RB_ROWS * RB_OUT_PITCH;
-    dim3 grid(tiles, bs * heads), block(256);
+    int land_blocks = 0;
+    if (v_buf) {
+        if (!v_host || !v_temp || !hit_offsets || (v_host_stride % 8) || (v_stride % 8) || (v_off % 8)) return SKV_ERR_ARG;
+        land_blocks = (S + 7) / 8;
+    }
+    dim3 grid(tiles + land_blocks, bs * heads), block(256);
 #define SKV_RB(M, K)                                                                                               \
     hipLaunchKernelGGL((skv_rebuild_kernel<M, K>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,     \
                        (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, ids64, cs_stride,    \
-                       out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets)
+                       out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets, tiles,    \
+                       (const u32x4*)v_host, (u32x4*)v_buf, (const u32x4*)v_temp, v_host_stride / 8, v_stride / 8, v_off / 8)
 #define SKV_RB_K(M)                 \
     switch (R / 32) {               \
         case 5: SKV_RB(M, 5); break; \

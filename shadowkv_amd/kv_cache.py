@@ -283,6 +283,21 @@ class ShadowKVCache_CPU:
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
+    def fetch_kv(self, layer_idx, position_ids, cos_sin_cache):
+        """get_value_cache + get_key_cache of one layer as a single launch on the current stream (K rebuild
+        tiles and V landing blocks run side by side inside one grid; no copy_stream fork/join).  Same bytes in
+        both caches as the two separate calls."""
+        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        vhost = self.v_cache_cpu[layer_idx]
+        U, SV = self.U[layer_idx], self.SV[layer_idx]
+        width = cos_sin_cache.shape[-1]
+        check(lib().skv_fetch_kv(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(position_ids), ptr(self.cnts),
+                                 ptr(self.offsets), ptr(kbuf), ptr(self._temp_k), ptr(vhost), ptr(vbuf),
+                                 ptr(self._temp_v), U.shape[0], self.num_key_value_heads, U.shape[1], self.head_dim,
+                                 self.rank, self.select_sets, self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0),
+                                 kbuf.stride(1), kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2,
+                                 vhost.stride(1), current_stream_handle()), "fetch_kv")
+
     def note_kv_appended(self, incoming=1):
         """Bookkeeping half of update_kv_cache for callers that wrote the new K / V rows themselves
         (tensor_op.qkv_rope_update pushes them from the fused QKV kernel): advances the offsets once per token."""

@@ -184,12 +184,11 @@ class DecoderLM:
     @torch.inference_mode()
     def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
         """Same computation as inference() for q_len == 1, with the small ops fused and the step's
-        scalars in device memory (graph-capturable): 13 launches per layer instead of ~40.
+        scalars in device memory (graph-capturable): 12 launches per layer instead of ~40.
           token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
           kv_len / kv_len_dev: rows attended (= row_idx + 1), q_table: optional [L, bs, Hq, 1, D] synthetic queries.
-        Per layer: [add+RMSNorm+QKV GEMV] -> split/RoPE/cache-push -> select (3) -> stage hits -> [side stream:
-        land V + PCIe fetch] || [land K + rebuild] -> attention (2) -> O GEMV -> [add+RMSNorm+gate/up GEMV+SiLU*mul]
-        -> down GEMV."""
+        Per layer: [add+RMSNorm+QKV GEMV] -> split/RoPE/cache-push -> select (3) -> stage hits -> [land K + rebuild
+        || land V + PCIe fetch, one launch] -> attention (2) -> O GEMV -> [add+RMSNorm+gate/up GEMV+SiLU*mul] -> down GEMV."""
         c = self.kv_cache
         x = F.embedding(token, self.embed_tokens)
         residual = None
@@ -204,11 +203,7 @@ class DecoderLM:
                                           c.v_cache_buffer[l], self.num_heads, self.num_key_value_heads,
                                           q_override=None if q_table is None else q_table[l])
             ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
-            with torch.cuda.stream(side):
-                side.wait_stream(cur)
-                c.get_value_cache(l, ids)
-            c.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=self.cos_sin_cache)
-            cur.wait_stream(side)
+            c.fetch_kv(l, ids, self.cos_sin_cache)
             attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,
                                                      kv_len_dev=kv_len_dev)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
@@ -354,20 +349,20 @@ class GraphDecoder:
         self.graph = None
 
     def _sample(self, logits):
+        """Same distribution as tensor_op.sample_token (top-k 50 -> top-p 0.9 -> multinomial): after the top-k
+        filter every other logit is -inf, so the nucleus is found among the k sorted survivors instead of sorting
+        the whole vocabulary (128K floats).  No host-side checks: graph-capturable."""
         if self.temperature == 0.0:
             return logits.argmax(dim=-1, keepdim=True)
-        logits = logits / self.temperature
-        if self.top_k > 0:
-            kth = torch.topk(logits, min(self.top_k, logits.size(-1)))[0][:, -1:]
-            logits = logits.masked_fill(logits < kth, float("-inf"))
+        k = min(self.top_k, logits.size(-1)) if self.top_k > 0 else logits.size(-1)
+        vals, idx = torch.topk(logits / self.temperature, k, dim=-1)          # sorted, descending
+        probs = F.softmax(vals, dim=-1)
         if self.top_p > 0.0:
-            sl, si = torch.sort(logits, descending=True)
-            rm = torch.cumsum(F.softmax(sl, dim=-1), dim=-1) > self.top_p
+            rm = torch.cumsum(probs, dim=-1) > self.top_p
             rm = torch.cat((torch.zeros_like(rm[..., :1]), rm[..., :-1]), dim=-1)
-            logits = logits.masked_fill(torch.zeros_like(rm).scatter(1, si, rm), float("-inf"))
-        probs = F.softmax(logits, dim=-1)
-        # multinomial(1) as torch implements it: argmax(p / Exp(1)), without host-side checks
-        return torch.argmax(probs / torch.empty_like(probs).exponential_(1.0), dim=-1, keepdim=True)
+            probs = F.softmax(vals.masked_fill(rm, float("-inf")), dim=-1)
+        pick = torch.argmax(probs / torch.empty_like(probs).exponential_(1.0), dim=-1, keepdim=True)  # = multinomial(1)
+        return idx.gather(-1, pick)
 
     def _body(self):
         m, c = self.m, self.m.kv_cache

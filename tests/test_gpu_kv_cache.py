@@ -126,3 +126,23 @@ def test_legacy_two_launch_key_path_equals_fused():
                                                     cache.sparse_end, cache.cnts)
     torch.cuda.synchronize()
     assert_bits_equal(k1, k2, "fused vs two-launch K rebuild")
+
+
+@pytest.mark.parametrize("case", ["llama_small", "glm_small"])
+def test_fetch_kv_single_launch_equals_two_calls(case):
+    """cache.fetch_kv (K rebuild tiles + V landing blocks in one grid) must leave the same bytes in both caches
+    as get_value_cache + get_key_cache."""
+    ca, c, inp = _build(case)
+    cb, _, _ = _build(case)
+    cs = inp["cos_sin"].to(DEV)
+    for t in range(3):
+        q = inp["q_steps"][t].to(DEV)
+        ida = ca.get_retrieval_position_ids(layer_idx=0, query_states=q)
+        idb = cb.get_retrieval_position_ids(layer_idx=0, query_states=q)
+        ca.get_value_cache(0, ida)
+        ca.get_key_cache(layer_idx=0, position_ids=ida, rope_func=None, cos_sin_cache=cs)
+        cb.fetch_kv(0, idb, cs)
+        torch.cuda.synchronize()
+        assert torch.equal(ca.position_ids, cb.position_ids)
+        assert_bits_equal(ca.k_cache_buffer, cb.k_cache_buffer, f"step {t}: K")
+        assert_bits_equal(ca.v_cache_buffer, cb.v_cache_buffer, f"step {t}: V")
