@@ -311,7 +311,7 @@ def main():
                           walk_step=args.walk_step)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and args.workload == "llama31_122k":
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:

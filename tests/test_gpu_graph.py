@@ -7,10 +7,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _make(seed=5):
+def _make(seed=5, glm=False):
     from shadowkv_amd import llama
     cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
-                            num_attention_heads=8, num_key_value_heads=2, vocab_size=2000)
+                            num_attention_heads=8, num_key_value_heads=2, vocab_size=2000,
+                            qkv_bias=glm, rope_style="glm" if glm else "neox")
     m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
                         seed=seed)
     llama.build_synthetic_context(m, 4608, seed=77)
@@ -48,13 +49,14 @@ def test_graph_equals_eager(use_walk):
     assert torch.equal(c1.v_cache_buffer.view(torch.int16), c2.v_cache_buffer.view(torch.int16))
 
 
-def test_fused_step_close_to_reference_call_order():
+@pytest.mark.parametrize("glm", [False, True])
+def test_fused_step_close_to_reference_call_order(glm):
     """forward_fused (fused small ops, device-side scalars) against the reference-shaped call order
     (inference -> layer_compute -> update_kv_cache / get_* methods, torch ops for norm / RoPE / SiLU).  The
     dense side differs only by op fusion (one rounding more or less per op), so logits must agree closely
     and the chunk selection of the first layer must be identical."""
-    m1, llama = _make()
-    m2, _ = _make()
+    m1, llama = _make(glm=glm)
+    m2, _ = _make(glm=glm)
     tok = torch.tensor([[23]], device=DEV)
     c1, c2 = m1.kv_cache, m2.kv_cache
     pos = m1.get_ctx(tok)

@@ -27,5 +27,11 @@ int main() {
         for (int i = 0; i < 12; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
         printf("\n");
     }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int it = 0; it < 50; ++it) skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, B, N, S, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("back-to-back launches: %.2f us per launch (event time, includes launch boundary)\n", ms * 1e3 / 50);
     return 0;
 }
