@@ -252,6 +252,15 @@ SKV_EXPORT int skv_gemv_bf16(const void* W, const void* x, const void* bias, voi
 SKV_EXPORT int skv_norm_gemv_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
                        void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul, skv_stream_t stream);
 
+/* [residual add + RMSNorm +] fused QKV projection of ONE token (bs == 1) with the split, RoPE and the cache append
+ * in the epilogue (= skv_norm_gemv_bf16 followed by skv_qkv_rope_update, one launch).  norm_weight NULL: x is used
+ * as is (then K is arbitrary, multiple of 512); otherwise K must be 4096. */
+SKV_EXPORT int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const void* residual, const void* norm_weight,
+                             float eps, void* h_out, const void* bias, const void* cos_sin, const int64_t* pos,
+                             const int64_t* row_idx, const void* q_override, void* q_out, void* k_cache, void* v_cache,
+                             int K, int q_heads, int kv_heads, int head_dim, long long cos_sin_stride,
+                             long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

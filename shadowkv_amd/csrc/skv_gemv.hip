@@ -18,13 +18,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the RMS statistics (its 64 lanes x 8 k-steps cover all 4096 elements) and xn = bf16(h * rstd * w_norm) in
 // registers, so "residual add + RMSNorm + projection" is one launch; block 0 / wave 0 stores h (the new
 // residual stream).  Same rounding points as the separate skv_add_rmsnorm launch.
-template <int R, bool SILU_PAIR, bool NORM>
+// QKV epilogue (QKV == true, W = fused [q; k; v] projection of ONE token, head_dim 128): the wave's 4 rows are two
+// rotation pairs of one head - NeoX: (t, t+64), (t+1, t+65); GLM: (2t', 2t'+1), (2t'+2, 2t'+3) - so lane 0 can rotate
+// q / k at the token's position and write q to q_out and k / v straight into the cache row: the projection, the
+// split, RoPE and update_kv_cache are one launch (same arithmetic as skv_qkv_rope_update_kernel).
+struct QkvEpilogue {
+    const bf16_t* cos_sin;
+    const int64_t* pos;       // [1]
+    const int64_t* row_idx;   // [1]
+    const bf16_t* q_override; // nullable [Hq][128]
+    bf16_t* q_out;            // [Hq][128]
+    bf16_t* k_cache;          // [Hkv][cache_rows][128]
+    bf16_t* v_cache;
+    long long cs_stride, cache_stride_h;
+    int Hq, Hkv, cache_rows, glm;
+};
+
+template <int R, bool SILU_PAIR, bool NORM, bool QKV>
 __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N,
                                                        int K, int I /* SILU_PAIR: rows of one half */,
                                                        const bf16_t* __restrict__ residual,
                                                        const bf16_t* __restrict__ w_norm, bf16_t* __restrict__ h_out,
-                                                       float eps) {
+                                                       float eps, QkvEpilogue qe) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksteps = NORM ? 8 : K / 512;  // 64 lanes x 8 elements per step (NORM: K == 4096, static trip count)
     // rows of this wave
@@ -33,7 +49,11 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (SILU_PAIR) rows[r] = (r & 1) ? I + unit0 + r / 2 : unit0 + r / 2;  // (gate, up) pairs
-        else rows[r] = unit0 + r;
+        else if (QKV && !qe.glm) {
+            // unit0 = 4 * wave index; wave index w -> head w / 32, t0 = 2 * (w % 32); rows t0, t0+64, t0+1, t0+65
+            const int w = unit0 / 4, head = w / 32, t0 = 2 * (w % 32);
+            rows[r] = head * 128 + t0 + (r >> 1) + ((r & 1) ? 64 : 0);
+        } else rows[r] = unit0 + r;
     }
     const int limit = SILU_PAIR ? I : N;
     if (unit0 >= limit) return;
@@ -130,6 +150,57 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
                   ((acc[r][2].x + acc[r][2].y) + (acc[r][3].x + acc[r][3].y));
         tot[r] = wave_tree_sum(s);
     }
+    if (QKV) {
+        if (lane == 0 && unit0 < N) {
+            const int head = unit0 / 128;                       // 4 rows of one head (unit0 % 4 == 0)
+            float o[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) o[r] = bfr(bias ? bfr(tot[r]) + bf2f(bias[rows[r]]) : tot[r]);  // the projection output is bf16
+            const long long row = *qe.row_idx;
+            if (head >= qe.Hq + qe.Hkv) {                       // V: copy into the cache row
+                if (row >= 0 && row < qe.cache_rows) {
+                    bf16_t* dst = qe.v_cache + (long long)(head - qe.Hq - qe.Hkv) * qe.cache_stride_h + row * 128;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[rows[r] - head * 128] = f2bf(o[r]);
+                }
+            } else {
+                const bf16_t* cs = qe.cos_sin + (*qe.pos) * qe.cs_stride;
+                float res[R];
+                int dim[R];
+#pragma unroll
+                for (int p = 0; p < R / 2; ++p) {
+                    const int d1 = rows[2 * p] - head * 128, d2 = rows[2 * p + 1] - head * 128;
+                    dim[2 * p] = d1; dim[2 * p + 1] = d2;
+                    const float x1 = o[2 * p], x2 = o[2 * p + 1];
+                    if (!qe.glm) {                              // pair (t, t+64)
+                        const float c = bf2f(cs[d1]), sn = bf2f(cs[d1 + 64]);
+                        res[2 * p] = bfr(x1 * c) + bfr(-x2 * sn);
+                        res[2 * p + 1] = bfr(x2 * c) + bfr(x1 * sn);
+                    } else if (d1 < 64) {                       // pair (2t, 2t+1), cos[t], sin[32+t]
+                        const float c = bf2f(cs[d1 >> 1]), sn = bf2f(cs[32 + (d1 >> 1)]);
+                        res[2 * p] = bfr(x1 * c) + bfr(-x2 * sn);
+                        res[2 * p + 1] = bfr(x2 * c) + bfr(x1 * sn);
+                    } else {
+                        res[2 * p] = x1; res[2 * p + 1] = x2;   // pass-through dims
+                    }
+                }
+                if (head < qe.Hq) {
+                    bf16_t* dst = qe.q_out + (size_t)head * 128;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float v = res[r];
+                        if (qe.q_override) v = bf2f(qe.q_override[(size_t)head * 128 + dim[r]]) + v * 0.0f;
+                        dst[dim[r]] = f2bf(v);
+                    }
+                } else if (row >= 0 && row < qe.cache_rows) {
+                    bf16_t* dst = qe.k_cache + (long long)(head - qe.Hq) * qe.cache_stride_h + row * 128;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[dim[r]] = f2bf(res[r]);
+                }
+            }
+        }
+        return;
+    }
     if (lane == 0) {
         if (SILU_PAIR) {
 #pragma unroll
@@ -151,14 +222,30 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
 }
 
 static int launch_gemv(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
-                       const void* residual, const void* w_norm, void* h_out, float eps, bool norm, hipStream_t st) {
-    if (!W || !x || !y || N < 1) return SKV_ERR_ARG;
+                       const void* residual, const void* w_norm, void* h_out, float eps, bool norm, hipStream_t st,
+                       const QkvEpilogue* qkv = nullptr) {
+    if (!W || !x || (!y && !qkv) || N < 1) return SKV_ERR_ARG;
+    QkvEpilogue qe{};
+    if (qkv) qe = *qkv;
     if (K % 512 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
 #define SKV_GEMV(SILU, NORMF, GRID, IARG)                                                                            \
-    hipLaunchKernelGGL((skv_gemv_kernel<4, SILU, NORMF>), dim3(GRID), dim3(256), 0, st, (const bf16_t*)W,             \
+    hipLaunchKernelGGL((skv_gemv_kernel<4, SILU, NORMF, false>), dim3(GRID), dim3(256), 0, st, (const bf16_t*)W,      \
                        (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, IARG, (const bf16_t*)residual,        \
-                       (const bf16_t*)w_norm, (bf16_t*)h_out, eps)
+                       (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe)
+    if (qkv) {
+        if (fuse_silu_mul || N != (qe.Hq + 2 * qe.Hkv) * 128) return SKV_ERR_ARG;
+        const int grid = (N + 15) / 16;
+        if (norm)
+            hipLaunchKernelGGL((skv_gemv_kernel<4, false, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)W,
+                               (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)nullptr, N, K, 0, (const bf16_t*)residual,
+                               (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe);
+        else
+            hipLaunchKernelGGL((skv_gemv_kernel<4, false, false, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)W,
+                               (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)nullptr, N, K, 0, (const bf16_t*)residual,
+                               (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe);
+        return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+    }
     if (fuse_silu_mul) {
         if (N % 2 || bias) return SKV_ERR_ARG;
         const int I = N / 2;
@@ -181,4 +268,18 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
                                   void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                                   skv_stream_t stream) {
     return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, residual, norm_weight, h_out, eps, true, (hipStream_t)stream);
+}
+
+extern "C" int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const void* residual, const void* norm_weight,
+                                        float eps, void* h_out, const void* bias, const void* cos_sin, const int64_t* pos,
+                                        const int64_t* row_idx, const void* q_override, void* q_out, void* k_cache,
+                                        void* v_cache, int K, int q_heads, int kv_heads, int head_dim,
+                                        long long cos_sin_stride, long long cache_stride_h, int cache_rows, int rope_mode,
+                                        skv_stream_t stream) {
+    if (!cos_sin || !pos || !row_idx || !q_out || !k_cache || !v_cache) return SKV_ERR_ARG;
+    if (head_dim != 128 || (rope_mode != 1 && rope_mode != 2)) return SKV_ERR_UNSUPPORTED;
+    QkvEpilogue qe{(const bf16_t*)cos_sin, pos, row_idx, (const bf16_t*)q_override, (bf16_t*)q_out, (bf16_t*)k_cache,
+                   (bf16_t*)v_cache, cos_sin_stride, cache_stride_h, q_heads, kv_heads, cache_rows, rope_mode == 2};
+    return launch_gemv(Wqkv, x, bias, nullptr, (q_heads + 2 * kv_heads) * 128, K, 0, residual, norm_weight, h_out, eps,
+                       norm_weight != nullptr, (hipStream_t)stream, &qe);
 }

@@ -184,7 +184,7 @@ class DecoderLM:
     @torch.inference_mode()
     def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
         """Same computation as inference() for q_len == 1, with the small ops fused and the step's
-        scalars in device memory (graph-capturable): 12 launches per layer instead of ~40.
+        scalars in device memory (graph-capturable): 12 launches per layer instead of ~40 (11 when bs == 1).
           token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
           kv_len / kv_len_dev: rows attended (= row_idx + 1), q_table: optional [L, bs, Hq, 1, D] synthetic queries.
         Per layer: [add+RMSNorm+QKV GEMV] -> split/RoPE/cache-push -> select (3) -> stage hits -> [land K + rebuild
@@ -197,11 +197,10 @@ class DecoderLM:
         bs = x.shape[0]
         c.incoming_q_len = 1
         for l, layer in enumerate(self.layers):
-            residual, qkv = tensor_op.norm_linear_decode(x, residual, layer.input_layernorm_weight,
-                                                          layer.input_layernorm_variance_epsilon, layer.wqkv, layer.bqkv)
-            q = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l],
-                                          c.v_cache_buffer[l], self.num_heads, self.num_key_value_heads,
-                                          q_override=None if q_table is None else q_table[l])
+            residual, q = tensor_op.norm_qkv_rope_update(
+                x, residual, layer.input_layernorm_weight, layer.input_layernorm_variance_epsilon, layer.wqkv,
+                layer.bqkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l], c.v_cache_buffer[l], self.num_heads,
+                self.num_key_value_heads, q_override=None if q_table is None else q_table[l])
             ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
             c.fetch_kv(l, ids, self.cos_sin_cache)
             attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,

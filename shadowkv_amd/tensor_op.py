@@ -100,6 +100,27 @@ def qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_he
     return q
 
 
+def norm_qkv_rope_update(x, residual, norm_w, eps, wqkv, bqkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads,
+                         kv_heads, q_override=None):
+    """(h, q) for ONE token of ONE sequence: h = x + residual, q = RoPE(split(linear(RMSNorm(h)))) [1, Hq, 1, D];
+    rotated k and v are pushed into row row_idx of k_cache / v_cache [1, Hkv, rows, D].  One native launch when the
+    hidden size is 4096 and bs == 1; otherwise norm_linear_decode + qkv_rope_update."""
+    K = x.shape[-1]
+    D = k_cache.shape[-1]
+    if x.numel() != K or K != 4096 or not x.is_contiguous() or not wqkv.is_contiguous() or D != 128:
+        h, qkv = norm_linear_decode(x, residual, norm_w, eps, wqkv, bqkv)
+        return h, qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_heads, q_override)
+    q = torch.empty(1, q_heads, 1, D, dtype=x.dtype, device=x.device)
+    h = torch.empty_like(x) if residual is not None else x
+    check(lib().skv_qkv_gemv_rope_update(ptr(wqkv), ptr(x), ptr(residual), ptr(norm_w), float(eps),
+                                         ptr(h) if residual is not None else 0, ptr(bqkv), ptr(cos_sin), ptr(pos),
+                                         ptr(row_idx), ptr(q_override), ptr(q), ptr(k_cache), ptr(v_cache), K, q_heads,
+                                         kv_heads, D, cos_sin.stride(0), k_cache.stride(1), k_cache.shape[2],
+                                         1 if cos_sin.shape[-1] == 128 else 2, current_stream_handle()),
+          "qkv_gemv_rope_update")
+    return h, q
+
+
 # ---------------------------------------------------------------------------- RoPE (pure torch, tensor_op.py:127-151)
 def rotate_half(x):
     half = x.shape[-1] // 2

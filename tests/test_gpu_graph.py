@@ -128,3 +128,28 @@ def test_norm_gemv_equals_separate_launches():
         assert torch.equal(h1.view(torch.int16), h2.view(torch.int16))
         # the RMS sum is reduced in a different order (one wave vs four): rstd may differ in its last bit
         assert torch.allclose(y1.float(), y2.float(), rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("glm", [False, True])
+def test_qkv_gemv_epilogue_equals_separate_kernels(glm):
+    """The QKV GEMV with split + RoPE + cache push in its epilogue must write exactly what the GEMV followed by
+    skv_qkv_rope_update writes (same rows per wave, same rotation arithmetic)."""
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(8 + glm)
+    Hq, Hkv, D, rows = 32, 4 if glm else 8, 128, 300
+    x = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    r = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(4096, device=DEV, generator=g)).bfloat16()
+    w = (torch.randn((Hq + 2 * Hkv) * D, 4096, device=DEV, generator=g) * 0.05).bfloat16()
+    b = (torch.randn((Hq + 2 * Hkv) * D, device=DEV, generator=g) * 0.1).bfloat16() if glm else None
+    cs = torch.randn(1000, 64 if glm else 128, device=DEV, generator=g).clamp(-1, 1).bfloat16()
+    pos = torch.tensor([[777]], device=DEV); row = torch.tensor([123], device=DEV)
+    k1 = torch.zeros(1, Hkv, rows, D, device=DEV, dtype=torch.bfloat16); v1 = torch.zeros_like(k1)
+    k2 = torch.zeros_like(k1); v2 = torch.zeros_like(k1)
+    h1, q1 = tensor_op.norm_qkv_rope_update(x, r, nw, 1e-5, w, b, cs, pos, row, k1, v1, Hq, Hkv)
+    h2, qkv = tensor_op.norm_linear_decode(x, r, nw, 1e-5, w, b)
+    q2 = tensor_op.qkv_rope_update(qkv, cs, pos, row, k2, v2, Hq, Hkv)
+    torch.cuda.synchronize()
+    for a, c in ((h1, h2), (q1, q2), (k1, k2), (v1, v2)):
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16))
+    assert int(k1[:, :, 123].abs().sum() > 0) and int(k1[:, :, :123].abs().sum()) == 0
