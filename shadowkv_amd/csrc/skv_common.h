@@ -159,6 +159,37 @@ __device__ __forceinline__ float wave_tree_sum(float v) {
     v = v + __shfl_xor(v, 32, 64);
     return v;
 }
+// wave-wide max / u64 sum: 4 DPP steps inside each 16-lane row, then the 4 row results through readlane
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    const int x = __float_as_int(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(x, 0)), b = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(x, 32)), d = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64_dpp(unsigned long long v) {
+    v += dpp_mov_u64<0xB1>(v);
+    v += dpp_mov_u64<0x4E>(v);
+    v += dpp_mov_u64<0x141>(v);
+    v += dpp_mov_u64<0x140>(v);
+    unsigned long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * r);
+        t += ((unsigned long long)hi << 32) | lo;
+    }
+    return t;
+}
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;

@@ -25,10 +25,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // in registers, two query heads per v_pk_fma_f32), and a 4-step DPP butterfly over the 16
 // lanes finishes the dot products; the butterfly transposes (each lane finishes ONE of the G
 // totals), so scaling, bf16 rounding and the LDS store happen once per lane, not G times.
-// 16 loads (64 rows per wave) are issued before the first use.
+// A tile is shared by 16 waves (16 rows = 4 loads each, all issued before the first use): many waves per SIMD
+// keep VALU issue dense while the tile streams in (with 4 waves x 16 loads: 2.85 TB/s).
 // ---------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256) void skv_score_tile_kernel(
+#ifndef SKV_SCORE_WAVES
+#define SKV_SCORE_WAVES 16                      // waves per 256-landmark tile (16 rows each; 4/8/16 measured: 9.3 / 8.8 / 8.5 us)
+#endif
+#define SKV_SCORE_ITERS (64 / SKV_SCORE_WAVES)   // 4-row wave-instructions per wave
+// ABL (ablation, diagnostic builds only - tools/score_probe.hip): 0 = the kernel; 1 = loads only (no dot
+// products); 2 = no per-tile statistics tail.  The library instantiates ABL = 0 only.
+template <int G, int ABL = 0>
+__global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
     const bf16_t* __restrict__ q,    // [B][G][128]
     const bf16_t* __restrict__ lm,   // [B][N][128]
     bf16_t* __restrict__ D,          // [B][G][N]
@@ -38,10 +45,7 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
     const int b = blockIdx.y, t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, rsel = lane >> 4;
-    __shared__ bf16_t sD[G][SKV_TILE];
-    __shared__ float s_red_m[4][G];
-    __shared__ unsigned long long s_red_s[4][G];
-    __shared__ float s_m[G];
+    __shared__ __attribute__((aligned(16))) bf16_t sD[G][SKV_TILE];
 
     // q fragment: G x 8 floats, packed in pairs of query heads for v_pk_fma_f32
     constexpr int GP = (G + 1) / 2;
@@ -57,18 +61,25 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
         }
     }
 
-    const int row0 = t * SKV_TILE + wave * 64 + rsel;
-    u32x4 x[16];
+    const int row0 = t * SKV_TILE + wave * (4 * SKV_SCORE_ITERS) + rsel;
+    u32x4 x[SKV_SCORE_ITERS];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < SKV_SCORE_ITERS; ++i) {
         int row = row0 + i * 4;
         row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
         x[i] = *reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub);
     }
     const int my_g = row16_owner<G>(lane);
     const bool publish = row16_publisher<G>(lane);
+    if (ABL == 1) {   // memory stream only: fold the loaded words so the loads stay, skip all arithmetic
+        uint32_t f = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < SKV_SCORE_ITERS; ++i) f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+        if (f == 0x12345u) D[0] = (bf16_t)f;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < SKV_SCORE_ITERS; ++i) {
         float xf[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -87,38 +98,47 @@ __global__ __launch_bounds__(256) void skv_score_tile_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g) part[g] = (g & 1) ? acc2[g / 2].y : acc2[g / 2].x;
         const float tot = row16_tree_sum_transposed<G>(part, lane);
-        if (publish) sD[my_g][wave * 64 + i * 4 + rsel] = f2bf(alpha * tot);
+        if (publish) sD[my_g][wave * (4 * SKV_SCORE_ITERS) + i * 4 + rsel] = f2bf(alpha * tot);
     }
     __syncthreads();
+    if (ABL == 2) {
+        if (tid < SKV_TILE && t * SKV_TILE + tid < N) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) D[((size_t)b * G + g) * N + t * SKV_TILE + tid] = sD[g][tid];
+        }
+        return;
+    }
 
-    // per-tile statistics; thread `tid` owns column `tid`
-    const int col = t * SKV_TILE + tid;
-    const bool valid = col < N;
-    float dv[G];
+    // per-tile statistics: wave w owns query head g = w (+ k*waves) and all 256 columns of the tile, 4 consecutive
+    // columns per lane, so max, integer exp-sum and the logit store need no cross-wave step and no further barrier
+    // (ablation, tools/score_probe.hip: the previous column-per-thread tail cost 3.5 of 11.5 us).
+    for (int g = wave; g < G; g += SKV_SCORE_WAVES) {
+        const int c0 = 4 * lane;
+        float dv[4];
+        float mloc = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        dv[g] = bf2f(sD[g][tid]);
-        float m = wave_max(valid ? dv[g] : -INFINITY);
-        if (lane == 0) s_red_m[wave][g] = m;
-    }
-    __syncthreads();
-    if (tid < G) {
-        float m = fmaxf(fmaxf(s_red_m[0][tid], s_red_m[1][tid]), fmaxf(s_red_m[2][tid], s_red_m[3][tid]));
-        s_m[tid] = m;
-    }
-    __syncthreads();
+        for (int k = 0; k < 4; ++k) {
+            dv[k] = bf2f(sD[g][c0 + k]);
+            if (t * SKV_TILE + c0 + k < N) mloc = fmaxf(mloc, dv[k]);
+        }
+        const float m = wave_max_dpp(mloc);
+        unsigned long long e = 0ull;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        unsigned long long e = valid ? exp_to_fixed(spec_exp(dv[g] - s_m[g])) : 0ull;
-        e = wave_sum_u64(e);
-        if (lane == 0) s_red_s[wave][g] = e;
-        if (valid) D[((size_t)b * G + g) * N + col] = sD[g][tid];
-    }
-    __syncthreads();
-    if (tid < G) {
-        unsigned long long S = s_red_s[0][tid] + s_red_s[1][tid] + s_red_s[2][tid] + s_red_s[3][tid];
-        part_max[((size_t)b * T + t) * G + tid] = s_m[tid];
-        part_sum[((size_t)b * T + t) * G + tid] = fixed_to_float(S);
+        for (int k = 0; k < 4; ++k)
+            if (t * SKV_TILE + c0 + k < N) e += exp_to_fixed(spec_exp(dv[k] - m));
+        e = wave_sum_u64_dpp(e);
+        bf16_t* drow = D + ((size_t)b * G + g) * N + (size_t)t * SKV_TILE + c0;
+        if (t * SKV_TILE + c0 + 3 < N && (((size_t)drow) & 7) == 0) {
+            *reinterpret_cast<u32x2*>(drow) = *reinterpret_cast<const u32x2*>(&sD[g][c0]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t * SKV_TILE + c0 + k < N) drow[k] = sD[g][c0 + k];
+        }
+        if (lane == 0) {
+            part_max[((size_t)b * T + t) * G + g] = m;
+            part_sum[((size_t)b * T + t) * G + g] = fixed_to_float(e);
+        }
     }
 }
 
@@ -535,7 +555,7 @@ static inline int next_pow2(int v) {
 template <int G>
 static int launch_score_g(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int N, int T,
                           float alpha, hipStream_t st) {
-    hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(256), 0, st, (const bf16_t*)q,
+    hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(64 * SKV_SCORE_WAVES), 0, st, (const bf16_t*)q,
                        (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha);
     return SKV_OK;
 }
