@@ -97,31 +97,42 @@ def measure_score_kernel(model, iters=3):
 
 
 def measure_path_only(model, walk, steps=8):
-    """Decode-path kernels alone (select -> V move || K move + rebuild -> attention), dense layers excluded."""
-    from shadowkv_amd import tensor_op
+    """The ShadowKV kernels of one token alone (per layer: select -> stage hits -> K rebuild || V fetch -> attention;
+    dense layers excluded), captured in a hipGraph like the full step.  Returns (ms per token, chunk hit rate)."""
+    from shadowkv_amd import llama, tensor_op
     cache = model.kv_cache
-    cur = torch.cuda.current_stream()
-    hits = torch.zeros((), device=model.device, dtype=torch.float32)
+    dev = model.device
+    table = llama.make_walk_table(model, steps + 2, step=walk.step, seed=4242)
+    step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+    hits = torch.zeros((), device=dev, dtype=torch.float32)
+    kv_len = torch.tensor([cache.sparse_end + 1], dtype=torch.int32, device=dev)
 
     def one_token():
-        nonlocal hits
-        walk.advance()
+        q_all = torch.index_select(table, 0, step_idx)[0]
         for l in range(model.num_layers):
-            q = walk.qb[l]
+            q = q_all[l]
             ids = cache.get_retrieval_position_ids(layer_idx=l, query_states=q)
-            hits += cache.cnts.sum()
-            with torch.cuda.stream(cache.copy_stream):
-                cache.copy_stream.wait_stream(cur)
-                v = cache.get_value_cache(l, ids)
-            k = cache.get_key_cache(layer_idx=l, position_ids=ids, rope_func=None, cos_sin_cache=model.cos_sin_cache)
-            cur.wait_stream(cache.copy_stream)
-            tensor_op.sparse_attention_decode(q, k, v)
-    one_token()
+            hits.add_(cache.cnts.sum())
+            cache.fetch_kv(l, ids, model.cos_sin_cache)
+            tensor_op.sparse_attention_decode(q, cache.k_cache_buffer[l], cache.v_cache_buffer[l], kv_len=0,
+                                              kv_len_dev=kv_len)
+        step_idx.copy_((step_idx + 1) % table.shape[0])
+
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.inference_mode():
+        one_token()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.inference_mode(), torch.cuda.graph(g, stream=s):
+        one_token()
+    g.replay()
     torch.cuda.synchronize()
     hits.zero_()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_token()
+        g.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     hit_rate = float(hits) / (steps * model.num_layers * cache.block_num * cache.select_sets)
