@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: the decode step is captured once into a hipGraph and replayed (default); "
                          "eager: every launch issued from Python each step")
+    ap.add_argument("--attn", default="shadowkv", choices=["shadowkv", "full"],
+                    help="full: the reference's full-attention baseline (KV_Cache, every key attended) on the same model")
     ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
     ap.add_argument("--walk-step", type=float, default=0.3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,12 +239,19 @@ def main():
     cfg_name, ctx, budget = WORKLOADS[args.workload]
     cfg = getattr(llama, cfg_name)
     t_build = time.perf_counter()
+    full = args.attn == "full"
     model = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
-                            chunk_size=8, num_layers=args.layers, seed=1234 + rank)
-    llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
+                            chunk_size=8, num_layers=args.layers, seed=1234 + rank,
+                            attn_mode="full" if full else "shadowkv_cpu")
+    if full:
+        llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
+        args.no_extras = True
+        args.no_cpu_baseline = True
+    else:
+        llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
     walk = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
     cache = model.kv_cache
-    slack = cache.k_cache_buffer.shape[-2] - cache.sparse_end
+    slack = (cache.k_cache.shape[-2] - ctx) if full else (cache.k_cache_buffer.shape[-2] - cache.sparse_end)
     t_build = time.perf_counter() - t_build
 
     next_token = torch.randint(0, cfg.vocab_size, (1, 1), device=dev)
@@ -267,7 +276,10 @@ def main():
         if dec is not None:
             next_token = dec.step()
         else:
-            if cache.gen_offset >= slack:             # generated-token slack (96 rows at 122K) exhausted: the
+            if full:
+                if cache.kv_offset - ctx >= slack:
+                    cache.kv_offset = ctx
+            elif cache.gen_offset >= slack:           # generated-token slack (96 rows at 122K) exhausted: the
                 cache.gen_offset = 0                  # reference silently drops further rows; rewind the
                 cache.kv_offset = ctx                 # bookkeeping instead so every step does full work
             if args.query_mode == "walk":
@@ -303,7 +315,7 @@ def main():
     if rank == 0:
         from shadowkv_amd import _lib
         assert _lib.lib().skv_move_timeout_flag() == 0, "row mover spin timed out: results invalid"
-        roof = measure_score_kernel(model)
+        roof = measure_score_kernel(model) if not full else None
         extras = {}
         if not args.no_extras:
             path_ms, hit_rate = measure_path_only(model, walk)
@@ -328,8 +340,9 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "decode tokens/sec @122K ctx, Llama-3.1-8B, budget=2048 rank=160; 1/2/4/8 GPU"
-            if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}",
+            "metric": ("decode tokens/sec @122K ctx, Llama-3.1-8B, budget=2048 rank=160; 1/2/4/8 GPU"
+                       if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}")
+            if not full else f"decode tokens/sec, FULL-ATTENTION baseline, {args.workload}",
             "value": round(value, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -337,11 +350,12 @@ def main():
                                    f"chunk_size 8, bs 1 per GPU, {model.num_layers} layers"
                                    + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
-            "roofline": {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
-                         "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]},
         }
+        if roof is not None:
+            out["roofline"] = {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
+                               "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, walk)

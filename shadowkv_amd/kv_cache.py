@@ -34,6 +34,57 @@ from . import tensor_op
 from ._lib import lib, check, ptr, current_stream_handle
 
 
+class KV_Cache:
+    """Full-attention KV cache (the baseline `attn_mode='full'` of the reference, kv_cache.py:32-153): same
+    constructor and methods; K / V live in HBM from the start (the reference keeps them on the CPU until H2D())."""
+
+    def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16):
+        self.config = config
+        self.max_length = max_length
+        self.device = torch.device(device)
+        self.dtype = dtype
+        kv, D = config.num_key_value_heads, config.hidden_size // config.num_attention_heads
+        self.k_cache = torch.zeros(config.num_hidden_layers, batch_size, kv, max_length, D, device=self.device, dtype=dtype)
+        self.v_cache = torch.zeros(config.num_hidden_layers, batch_size, kv, max_length, D, device=self.device, dtype=dtype)
+        self.num_layers = config.num_hidden_layers
+        self.kv_offset = 0
+        self.prefilled_batch = 0
+        self.batch_size = batch_size
+
+    def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
+        bsz, _, incoming, _ = new_v_cache.shape
+        if bsz == self.batch_size:
+            self.prefilled_batch = 0
+        b0, lo = self.prefilled_batch, self.kv_offset
+        self.k_cache[layer_idx][b0:b0 + bsz, :, lo:lo + incoming].copy_(new_k_cache)
+        self.v_cache[layer_idx][b0:b0 + bsz, :, lo:lo + incoming].copy_(new_v_cache)
+        key = self.k_cache[layer_idx][b0:b0 + bsz, :, :lo + incoming]
+        value = self.v_cache[layer_idx][b0:b0 + bsz, :, :lo + incoming]
+        if layer_idx == self.num_layers - 1:
+            self.prefilled_batch += bsz
+            if self.prefilled_batch == self.batch_size:
+                self.kv_offset += incoming
+        return key, value
+
+    def note_kv_appended(self, incoming=1):
+        self.kv_offset += incoming
+
+    def print_stats(self):
+        print(f"KVCache | max_length {self.max_length} | dtype {self.dtype} | cached {self.kv_offset}")
+
+    def H2D(self):
+        gc.collect()
+
+    def clear(self):
+        self.k_cache.zero_()
+        self.v_cache.zero_()
+        self.kv_offset = 0
+        self.prefilled_batch = 0
+
+    def get_kv_len(self):
+        return self.kv_offset
+
+
 class ShadowKVCache_CPU:
     def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  sparse_budget=2048, chunk_size=8, rank=160):

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import tensor_op
-from .kv_cache import ShadowKVCache_CPU
+from .kv_cache import KV_Cache, ShadowKVCache_CPU
 
 
 @dataclass
@@ -79,8 +79,9 @@ class DecoderLM:
     def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
                  num_layers=None):
-        if attn_mode != "shadowkv_cpu":
-            raise ValueError("this build covers the ShadowKV offload decode path (attn_mode='shadowkv_cpu')")
+        if attn_mode not in ("shadowkv_cpu", "full"):
+            raise ValueError("attn_mode must be 'shadowkv_cpu' (ShadowKV offload path) or 'full' (full-attention baseline)")
+        self.attn_mode = attn_mode
         self.cfg = cfg
         self.config = cfg
         self.batch_size, self.max_length = batch_size, max_length
@@ -109,8 +110,13 @@ class DecoderLM:
             num_key_value_heads = cfg.num_key_value_heads
             hidden_size = cfg.hidden_size
 
-        self.kv_cache = ShadowKVCache_CPU(_CacheCfg, batch_size=batch_size, max_length=max_length, device=device,
-                                          dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size, rank=rank)
+        if attn_mode == "full":
+            self.kv_cache = KV_Cache(_CacheCfg, batch_size=batch_size, max_length=max_length + 1024, device=device,
+                                     dtype=dtype)
+        else:
+            self.kv_cache = ShadowKVCache_CPU(_CacheCfg, batch_size=batch_size, max_length=max_length, device=device,
+                                              dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size,
+                                              rank=rank)
         self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
 
     def weight_bytes(self):
@@ -192,19 +198,20 @@ class DecoderLM:
         c = self.kv_cache
         x = F.embedding(token, self.embed_tokens)
         residual = None
-        cur = torch.cuda.current_stream()
-        side = c.copy_stream
         bs = x.shape[0]
+        full = self.attn_mode == "full"
         c.incoming_q_len = 1
         for l, layer in enumerate(self.layers):
+            kbuf = c.k_cache[l] if full else c.k_cache_buffer[l]
+            vbuf = c.v_cache[l] if full else c.v_cache_buffer[l]
             residual, q = tensor_op.norm_qkv_rope_update(
                 x, residual, layer.input_layernorm_weight, layer.input_layernorm_variance_epsilon, layer.wqkv,
-                layer.bqkv, self.cos_sin_cache, pos, row_idx, c.k_cache_buffer[l], c.v_cache_buffer[l], self.num_heads,
+                layer.bqkv, self.cos_sin_cache, pos, row_idx, kbuf, vbuf, self.num_heads,
                 self.num_key_value_heads, q_override=None if q_table is None else q_table[l])
-            ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
-            c.fetch_kv(l, ids, self.cos_sin_cache)
-            attn = tensor_op.sparse_attention_decode(q, c.k_cache_buffer[l], c.v_cache_buffer[l], kv_len=kv_len,
-                                                     kv_len_dev=kv_len_dev)
+            if not full:
+                ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+                c.fetch_kv(l, ids, self.cos_sin_cache)
+            attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
             # (the norm prologue is NOT fused into this GEMV: measured 47 us fused vs 5 + 37 us separate -
             #  7168 waves each redoing the 4096-element statistics cost more than the launch they save)
@@ -236,7 +243,7 @@ class DecoderLM:
             logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
         else:
             c = self.kv_cache
-            row = c.sparse_end + c.gen_offset
+            row = c.kv_offset if self.attn_mode == "full" else c.sparse_end + c.gen_offset
             pos = self.get_ctx(next_token)
             row_idx = torch.tensor([row], device=self.device, dtype=torch.long)
             logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table)
@@ -293,6 +300,19 @@ def build_synthetic_context(model, context_len, seed=1234, q_scale=0.25):
     return q_last
 
 
+@torch.inference_mode()
+def build_synthetic_context_full(model, context_len, seed=1234):
+    """Full-attention baseline: fills the KV cache with `context_len` synthetic tokens (K, V ~ N(0,1) bf16)."""
+    c = model.kv_cache
+    for l in range(model.num_layers):
+        g = torch.Generator(device=model.device).manual_seed(seed + l)
+        for t in (c.k_cache, c.v_cache):
+            t[l][:, :, :context_len].copy_(torch.randn(t[l][:, :, :context_len].shape, device=model.device,
+                                                       generator=g).to(model.dtype))
+    c.kv_offset = context_len
+    torch.cuda.synchronize(model.device)
+
+
 class QueryWalk:
     """Synthetic per-layer query trajectory: q_t = normalize(q_{t-1} + step*N(0,1)) * |q|,
     so consecutive selections overlap like a real model's; `step` tunes the chunk hit rate.  Used as
@@ -338,11 +358,15 @@ class GraphDecoder:
         self.temperature, self.top_p, self.top_k = temperature, top_p, top_k
         c = model.kv_cache
         dev = model.device
-        self.slack = c.k_cache_buffer.shape[-2] - c.sparse_end
+        self.full = model.attn_mode == "full"
+        if self.full:                      # rows [ctx, ctx + slack) receive the generated tokens, then wrap
+            self.base, self.slack, gen0 = c.kv_offset, c.k_cache.shape[-2] - c.kv_offset, 0
+        else:
+            self.base, self.slack, gen0 = c.sparse_end, c.k_cache_buffer.shape[-2] - c.sparse_end, c.gen_offset
         self.token = torch.zeros(model.batch_size, 1, dtype=torch.long, device=dev)
         self.pos = torch.full((model.batch_size, 1), c.kv_offset, dtype=torch.long, device=dev)
-        self.gen = torch.full((1,), c.gen_offset, dtype=torch.long, device=dev)
-        self.row_idx = self.gen + c.sparse_end
+        self.gen = torch.full((1,), gen0, dtype=torch.long, device=dev)
+        self.row_idx = self.gen + self.base
         self.kv_len = (self.row_idx + 1).to(torch.int32)
         self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
         self.walk_table = walk_table                     # [T, L, bs, Hq, 1, D] or None
@@ -375,7 +399,7 @@ class GraphDecoder:
         # advance the device-side counters (generated-row slack wraps like the host bookkeeping in step())
         self.pos.add_(1)
         self.gen.copy_((self.gen + 1) % self.slack)
-        self.row_idx.copy_(self.gen + c.sparse_end)
+        self.row_idx.copy_(self.gen + self.base)
         self.kv_len.copy_((self.row_idx + 1).to(torch.int32))
         if self.walk_table is not None:
             self.step_idx.copy_((self.step_idx + 1) % self.walk_table.shape[0])
@@ -383,7 +407,8 @@ class GraphDecoder:
     def _host_advance(self):
         c = self.m.kv_cache
         c.kv_offset += 1
-        c.gen_offset = (c.gen_offset + 1) % self.slack
+        if not self.full:
+            c.gen_offset = (c.gen_offset + 1) % self.slack
 
     @torch.inference_mode()
     def capture(self, warmup=2):

@@ -153,3 +153,34 @@ def test_qkv_gemv_epilogue_equals_separate_kernels(glm):
     for a, c in ((h1, h2), (q1, q2), (k1, k2), (v1, v2)):
         assert torch.equal(a.view(torch.int16), c.view(torch.int16))
     assert int(k1[:, :, 123].abs().sum() > 0) and int(k1[:, :, :123].abs().sum()) == 0
+
+
+def test_full_attention_baseline_graph_equals_eager_and_torch():
+    """attn_mode='full' (KV_Cache): graph == eager, and one step's logits agree with a torch SDPA evaluation."""
+    from shadowkv_amd import llama
+    cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
+                            num_attention_heads=8, num_key_value_heads=2, vocab_size=2000)
+    def make():
+        m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=3000, device=DEV, attn_mode="full", seed=5)
+        llama.build_synthetic_context_full(m, 3000, seed=9)
+        return m
+    m1, m2 = make(), make()
+    tok0 = torch.tensor([[11]], device=DEV)
+    t = tok0.clone(); toks1 = []
+    for _ in range(5):
+        t = m1.decode_step(t, temperature=0.0); toks1.append(int(t))
+    dec = llama.GraphDecoder(m2, temperature=0.0); dec.token.copy_(tok0)
+    warm = dec.capture(warmup=2)
+    toks2 = [int(dec.step()) for _ in range(5 - warm)]
+    torch.cuda.synchronize()
+    assert toks2 == toks1[warm:]
+    assert m1.kv_cache.kv_offset == m2.kv_cache.kv_offset == 3005
+    assert torch.equal(m1.kv_cache.k_cache.view(torch.int16), m2.kv_cache.k_cache.view(torch.int16))
+    # attention of the fused step vs torch on the same cache (layer 0 of a fresh model)
+    from shadowkv_amd import tensor_op
+    m3 = make()
+    q = torch.randn(1, 8, 1, 128, device=DEV).bfloat16()
+    out = tensor_op.sparse_attention_decode(q, m3.kv_cache.k_cache[0], m3.kv_cache.v_cache[0], kv_len=3000)
+    k = m3.kv_cache.k_cache[0][:, :, :3000].float().repeat_interleave(4, 1); v = m3.kv_cache.v_cache[0][:, :, :3000].float().repeat_interleave(4, 1)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k, v).transpose(1, 2)
+    assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-3)
