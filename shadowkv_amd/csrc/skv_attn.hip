@@ -56,29 +56,57 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     }
     const bf16_t* kb = k + (size_t)bh * kv_stride_h + 8 * sub;
     const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
-    for (int key = k0 + grp; key < k1; key += AT_GROUPS) {
-        u32x4 kr = *reinterpret_cast<const u32x4*>(kb + (size_t)key * AT_D);
-        u32x4 vr = *reinterpret_cast<const u32x4*>(vb + (size_t)key * AT_D);
-        float kf[8], vf[8];
+    // A 16-lane group takes AT_KB keys per iteration (keys grp + 16*i): 2*AT_KB row loads in flight, the scores of
+    // the batch are reduced first, then ONE running-max update / accumulator rescale per batch instead of per key.
+    constexpr int AT_KB = 4;
+    for (int key0 = k0 + grp; key0 < k1; key0 += AT_GROUPS * AT_KB) {
+        u32x4 kr[AT_KB], vr[AT_KB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kf[2 * j] = bf_lo(kr[j]);
-            kf[2 * j + 1] = bf_hi(kr[j]);
-            vf[2 * j] = bf_lo(vr[j]);
-            vf[2 * j + 1] = bf_hi(vr[j]);
+        for (int i = 0; i < AT_KB; ++i) {
+            const int key = key0 + i * AT_GROUPS;
+            const int kc = key < k1 ? key : k1 - 1;          // clamp; masked below
+            kr[i] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * AT_D);
+            vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * AT_D);
+        }
+        float sc[AT_KB][G];
+#pragma unroll
+        for (int i = 0; i < AT_KB; ++i) {
+            float kf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bf_lo(kr[i][j]);
+                kf[2 * j + 1] = bf_hi(kr[i][j]);
+            }
+            const bool live = key0 + i * AT_GROUPS < k1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = __builtin_fmaf(qf[g][j], kf[j], s);
+                s = row16_tree_sum(s);
+                sc[i][g] = live ? s : -INFINITY;
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s = 0.f;
+            float mn = m[g];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s = __builtin_fmaf(qf[g][j], kf[j], s);
-            s = row16_tree_sum(s);
-            float mn = fmaxf(m[g], s);
-            float corr = __expf(m[g] - mn);
-            float p = __expf(s - mn);
-            l[g] = l[g] * corr + p;
+            for (int i = 0; i < AT_KB; ++i) mn = fmaxf(mn, sc[i][g]);
+            const float corr = __expf(m[g] - mn);              // m = -inf on the first batch: exp(-inf) = 0
+            float lsum = l[g] * corr;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[g][j] = __builtin_fmaf(p, vf[j], acc[g][j] * corr);
+            for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
+#pragma unroll
+            for (int i = 0; i < AT_KB; ++i) {
+                const float p = __expf(sc[i][g] - mn);         // masked keys: exp(-inf) = 0
+                lsum += p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[g][2 * j] = __builtin_fmaf(p, bf_lo(vr[i][j]), acc[g][2 * j]);
+                    acc[g][2 * j + 1] = __builtin_fmaf(p, bf_hi(vr[i][j]), acc[g][2 * j + 1]);
+                }
+            }
+            l[g] = lsum;
             m[g] = mn;
         }
     }
