@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: the decode step is captured once into a hipGraph and replayed (default); "
                          "eager: every launch issued from Python each step")
+    ap.add_argument("--batch", type=int, default=1, help="sequences per GPU (headline metric: 1)")
     ap.add_argument("--attn", default="shadowkv", choices=["shadowkv", "full"],
                     help="full: the reference's full-attention baseline (KV_Cache, every key attended) on the same model")
     ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
@@ -240,9 +241,12 @@ def main():
     cfg = getattr(llama, cfg_name)
     t_build = time.perf_counter()
     full = args.attn == "full"
-    model = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
+    bs = args.batch
+    model = llama.DecoderLM(cfg=cfg, batch_size=bs, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
                             chunk_size=8, num_layers=args.layers, seed=1234 + rank,
                             attn_mode="full" if full else "shadowkv_cpu")
+    if bs > 1:
+        args.no_cpu_baseline = True
     if full:
         llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
         args.no_extras = True
@@ -254,7 +258,7 @@ def main():
     slack = (cache.k_cache.shape[-2] - ctx) if full else (cache.k_cache_buffer.shape[-2] - cache.sparse_end)
     t_build = time.perf_counter() - t_build
 
-    next_token = torch.randint(0, cfg.vocab_size, (1, 1), device=dev)
+    next_token = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
     tokens = []
     mode = args.mode
     dec = None
@@ -308,7 +312,7 @@ def main():
         elapsed_max = float(t)
     else:
         elapsed_max = elapsed
-    value = aggregate_throughput([args.steps] * world, [elapsed_max])
+    value = aggregate_throughput([args.steps * bs] * world, [elapsed_max])
     ms_per_step = elapsed_max / args.steps * 1e3
 
     out = None
@@ -347,7 +351,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
-                                   f"chunk_size 8, bs 1 per GPU, {model.num_layers} layers"
+                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers"
                                    + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
         }

@@ -412,6 +412,11 @@ class GraphDecoder:
 
     @torch.inference_mode()
     def capture(self, warmup=2):
+        if self.m.batch_size > 1 and self.m.hidden_size >= 4096:
+            # OPEN ISSUE (round 1): replaying the captured step with bs > 1 at full model shapes ends in a GPU
+            # memory fault (eager bs > 1 and captured bs > 1 on small shapes are correct and tested); refuse
+            # rather than fault.  Callers fall back to the eager step.
+            raise NotImplementedError("GraphDecoder: bs > 1 at full model shapes is not validated; use eager decode_step")
         s = torch.cuda.Stream(device=self.m.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
