@@ -380,7 +380,7 @@ class GraphDecoder:
         if self.temperature == 0.0:
             return logits.argmax(dim=-1, keepdim=True)
         k = min(self.top_k, logits.size(-1)) if self.top_k > 0 else logits.size(-1)
-        vals, idx = torch.topk(logits / self.temperature, k, dim=-1)          # sorted, descending
+        vals, idx = self._topk(logits / self.temperature, k)                  # sorted, descending
         probs = F.softmax(vals, dim=-1)
         if self.top_p > 0.0:
             rm = torch.cumsum(probs, dim=-1) > self.top_p
@@ -388,6 +388,24 @@ class GraphDecoder:
             probs = F.softmax(vals.masked_fill(rm, float("-inf")), dim=-1)
         pick = torch.argmax(probs / torch.empty_like(probs).exponential_(1.0), dim=-1, keepdim=True)  # = multinomial(1)
         return idx.gather(-1, pick)
+
+    @staticmethod
+    def _topk(x, k, parts=64):
+        """torch.topk(x, k, dim=-1) as two levels of short-slice top-k: top-k of each of `parts` slices, then top-k of
+        the parts*k survivors (the global top-k is a subset of them).  Not only cheaper than one radix select over the
+        whole vocabulary: PyTorch's multi-block top-k with more than one slice faults under hipGraph replay on this
+        ROCm build (tools/topk_graph_probe.py, pure PyTorch) - short slices take its single-block path."""
+        bs, V = x.shape
+        if V % parts or V // parts < k or V < 16384:
+            if bs == 1 or V < 16384:
+                return torch.topk(x, k, dim=-1)
+            rows = [torch.topk(x[b:b + 1], k, dim=-1) for b in range(bs)]     # one slice per call
+            return torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
+        w = V // parts
+        v1, i1 = torch.topk(x.view(bs, parts, w), k, dim=-1)                   # [bs, parts, k]
+        i1 = i1 + (torch.arange(parts, device=x.device) * w).view(1, parts, 1)
+        v2, i2 = torch.topk(v1.reshape(bs, parts * k), k, dim=-1)
+        return v2, i1.reshape(bs, parts * k).gather(-1, i2)
 
     def _body(self):
         m, c = self.m, self.m.kv_cache
@@ -412,11 +430,6 @@ class GraphDecoder:
 
     @torch.inference_mode()
     def capture(self, warmup=2):
-        if self.m.batch_size > 1 and self.m.hidden_size >= 4096:
-            # OPEN ISSUE (round 1): replaying the captured step with bs > 1 at full model shapes ends in a GPU
-            # memory fault (eager bs > 1 and captured bs > 1 on small shapes are correct and tested); refuse
-            # rather than fault.  Callers fall back to the eager step.
-            raise NotImplementedError("GraphDecoder: bs > 1 at full model shapes is not validated; use eager decode_step")
         s = torch.cuda.Stream(device=self.m.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

@@ -222,3 +222,17 @@ def test_batched_decode_matches_single_sequences():
         assert torch.equal(mb.kv_cache.v_cache_buffer[:, b].view(torch.int16), singles[b].kv_cache.v_cache_buffer[:, 0].view(torch.int16))
         # dense projections run through hipBLASLt for bs = 2 and the native GEMV for bs = 1: K rows agree closely
         assert torch.allclose(mb.kv_cache.k_cache_buffer[:, b].float(), singles[b].kv_cache.k_cache_buffer[:, 0].float(), rtol=0.05, atol=0.05)
+
+
+@pytest.mark.gpu
+def test_two_level_topk_matches_torch_topk():
+    """GraphDecoder._topk (short-slice two-level top-k, used because PyTorch's multi-slice multi-block top-k faults
+    under hipGraph replay on this ROCm build) returns torch.topk's values, and indices pointing at them."""
+    from shadowkv_amd.llama import GraphDecoder
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for bs, V in ((1, 128256), (3, 128256), (2, 151552), (2, 2000), (2, 20001)):
+        x = torch.randn(bs, V, device="cuda:0", generator=g)
+        v, i = GraphDecoder._topk(x, 50)
+        vr, _ = torch.topk(x, 50, dim=-1)
+        assert torch.equal(v, vr)
+        assert torch.equal(x.gather(-1, i), v)
