@@ -35,13 +35,13 @@ def silu_and_mul(out, x):
     return out
 
 
-MAX_GEMV_ROWS = 8   # small batches: one native GEMV per token row (no hipBLASLt in the captured decode step)
+MAX_GEMV_ROWS = 16   # small batches: one native GEMV per token row (no hipBLASLt in the captured decode step)
 
 
 def linear_decode(x, w, bias=None, fuse_silu_mul=False):
-    """F.linear for decode-time activations (x [..., K] with a handful of token rows) on the native GEMV, one
-    launch per row; falls back to F.linear for more than MAX_GEMV_ROWS rows or shapes the kernel is not built
-    for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
+    """F.linear for decode-time activations (x [..., K] with a handful of token rows): one token -> the native GEMV,
+    2..MAX_GEMV_ROWS tokens -> the native small-M MFMA kernel (weights stream once); falls back to F.linear for more
+    rows or shapes the kernels are not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
     K = x.shape[-1]
     rows = x.numel() // K
     if rows > MAX_GEMV_ROWS or K % 512 or not x.is_contiguous() or not w.is_contiguous():
@@ -50,11 +50,12 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False):
     N = w.shape[0]
     No = (N // 2) if fuse_silu_mul else N
     y = torch.empty(x.shape[:-1] + (No,), dtype=x.dtype, device=x.device)
-    L, st = lib(), current_stream_handle()
-    xp, yp, esz = x.data_ptr(), y.data_ptr(), x.element_size()
-    for r in range(rows):
-        check(L.skv_gemv_bf16(ptr(w), xp + r * K * esz, ptr(bias), yp + r * No * esz, N, K, 1 if fuse_silu_mul else 0, st),
-              "gemv")
+    if rows == 1:
+        check(lib().skv_gemv_bf16(ptr(w), ptr(x), ptr(bias), ptr(y), N, K, 1 if fuse_silu_mul else 0,
+                                  current_stream_handle()), "gemv")
+    else:
+        check(lib().skv_linear_rows_bf16(ptr(w), ptr(x), ptr(bias), ptr(y), rows, N, K, 1 if fuse_silu_mul else 0,
+                                         current_stream_handle()), "linear_rows")
     return y
 
 

@@ -114,6 +114,45 @@ def test_gemv_against_f32_reference(N, K, silu):
     assert torch.allclose(y.view(-1).float(), ref, rtol=2 ** -6, atol=2e-2), float((y.view(-1).float() - ref).abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,silu", [(2, 6144, 4096, False), (3, 4096, 14336, False), (8, 28672, 4096, True),
+                                        (16, 4096, 4096, False), (5, 1000, 13696, False), (7, 2 * 1003, 1024, True),
+                                        (4, 128256, 4096, False)])
+def test_rows_gemm_against_f32_reference(M, N, K, silu):
+    """skv_linear_rows_bf16 (M <= 16 token rows on the MFMA N dimension) against an f32 matmul of the same bf16
+    inputs; tolerance = bf16 output rounding (2^-8 relative) + f32 accumulation noise.  Ragged N, K = 13696 (GLM)
+    and the tail of the split-K loop are covered; rows beyond M must stay untouched."""
+    from shadowkv_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    bias = None if silu else (torch.randn(N, device=DEV, generator=g) * 0.1).bfloat16()
+    No = N // 2 if silu else N
+    y = torch.full((M + 1, No), 7.0, device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().skv_linear_rows_bf16(_lib.ptr(w), _lib.ptr(x), _lib.ptr(bias), _lib.ptr(y), M, N, K,
+                                               1 if silu else 0, _lib.current_stream_handle()), "linear_rows")
+    ref = x.float() @ w.float().t()
+    if silu:
+        gte, up = ref[:, : N // 2].bfloat16().float(), ref[:, N // 2:].bfloat16().float()
+        ref = torch.nn.functional.silu(gte).bfloat16().float() * up
+    else:
+        ref = ref.bfloat16().float() + bias.float()
+    assert torch.all(y[M].float() == 7.0)
+    assert torch.allclose(y[:M].float(), ref, rtol=2 ** -6, atol=2e-2), float((y[:M].float() - ref).abs().max())
+
+
+def test_linear_decode_rows_close_to_single_token_gemv():
+    """2..16 token rows (MFMA kernel) against one native GEMV per row: same bf16 output up to accumulation order."""
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(21)
+    w = (torch.randn(6144, 4096, device=DEV, generator=g) * 0.05).bfloat16()
+    x = torch.randn(6, 1, 4096, device=DEV, generator=g).bfloat16()
+    y = tensor_op.linear_decode(x, w)
+    y1 = torch.cat([tensor_op.linear_decode(x[r:r + 1], w) for r in range(6)])
+    assert y.shape == y1.shape
+    assert torch.allclose(y.float(), y1.float(), rtol=2 ** -7, atol=1e-2)
+    assert (y.view(torch.int16) == y1.view(torch.int16)).float().mean() > 0.9
+
+
 def test_norm_gemv_equals_separate_launches():
     from shadowkv_amd import tensor_op
     g = torch.Generator(device=DEV).manual_seed(4)
@@ -220,7 +259,7 @@ def test_batched_decode_matches_single_sequences():
     for b in range(2):
         assert torch.equal(mb.kv_cache.position_ids[:, b], singles[b].kv_cache.position_ids[:, 0]), b
         assert torch.equal(mb.kv_cache.v_cache_buffer[:, b].view(torch.int16), singles[b].kv_cache.v_cache_buffer[:, 0].view(torch.int16))
-        # dense projections run through hipBLASLt for bs = 2 and the native GEMV for bs = 1: K rows agree closely
+        # dense projections run on the small-M MFMA kernel for bs = 2 and the native GEMV for bs = 1: K rows agree closely
         assert torch.allclose(mb.kv_cache.k_cache_buffer[:, b].float(), singles[b].kv_cache.k_cache_buffer[:, 0].float(), rtol=0.05, atol=0.05)
 
 
