@@ -85,9 +85,26 @@ class KV_Cache:
         return self.kv_offset
 
 
+def gram_factorize(k, rank):
+    """Rank-`rank` factors of k [bs, L, H] (f32, L >> H) without a full SVD: the right
+    singular vectors are the eigenvectors of the H x H Gram matrix K^T K (one tall-skinny GEMM; squaring the condition
+    number only hurts the small singular values, the leading `rank` pairs kept here are the well-conditioned ones), so
+        K^T K = V diag(s^2) V^T,   U_r = K V_r diag(1/s_r),   SV = diag(s_r) V_r^T,   U_r SV = K V_r V_r^T
+    which is the same best rank-r approximation torch.svd gives (columns may differ by sign, the product does not).
+    Two GEMMs of L x H x H / L x H x r and an H x H eigh instead of rocSOLVER's gesvd over the L x H matrix.
+    Returns (U_r [bs, L, rank], SV [bs, rank, H]) in f32."""
+    g = torch.matmul(k.transpose(1, 2), k)                                  # [bs, H, H]
+    lam, vec = torch.linalg.eigh(g)                                         # ascending
+    lam_r = lam[:, -rank:].flip(-1).clamp_min(0)
+    v_r = vec[:, :, -rank:].flip(-1)                                        # [bs, H, rank], descending s
+    s_r = lam_r.sqrt()
+    u_r = torch.matmul(k, v_r) / s_r.clamp_min(torch.finfo(torch.float32).tiny).unsqueeze(1)
+    return u_r, v_r.transpose(1, 2) * s_r.unsqueeze(-1)
+
+
 class ShadowKVCache_CPU:
     def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
-                 sparse_budget=2048, chunk_size=8, rank=160):
+                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd"):
         if dtype != torch.bfloat16:
             raise ValueError("ShadowKVCache_CPU supports bfloat16 only (as the reference's kernels do)")
         self.config = config
@@ -104,6 +121,9 @@ class ShadowKVCache_CPU:
         self.sparse_budget = int(sparse_budget)
         self.chunk_size = chunk_size
         self.rank = rank
+        if svd_mode not in ("svd", "gram"):
+            raise ValueError("svd_mode must be 'svd' (torch.svd, the reference) or 'gram' (K^T K eigendecomposition)")
+        self.svd_mode = svd_mode
         self.local_chunk = 4
         self.outlier_chunk = int((self.sparse_budget // 1024) * 24)
         self.select_sets = self.sparse_budget // self.chunk_size
@@ -188,13 +208,19 @@ class ShadowKVCache_CPU:
             self.U = torch.zeros(self.num_layers, self.batch_size, seq, self.rank, device=self.device, dtype=self.dtype)
             self.SV = torch.zeros(self.num_layers, self.batch_size, kv, D, self.rank, device=self.device,
                                   dtype=self.dtype)
-        u, s, v = torch.svd(k.float())
         r = self.rank
         b0 = self.prefilled_batch
-        self.U[layer_idx][b0:b0 + bsz].copy_(u[:, :, :r].to(self.dtype))
-        sv = torch.matmul(torch.diag_embed(s[:, :r]), v.transpose(1, 2)[:, :r]).to(self.dtype)  # [bs, r, kv*D]
+        kf = k.float()
+        if self.svd_mode == "svd":
+            u, s, v = torch.svd(kf)
+            self.U[layer_idx][b0:b0 + bsz].copy_(u[:, :, :r].to(self.dtype))
+            sv = torch.matmul(torch.diag_embed(s[:, :r]), v.transpose(1, 2)[:, :r]).to(self.dtype)  # [bs, r, kv*D]
+            del u, s, v
+        else:
+            u_r, sv = gram_factorize(kf, r)
+            self.U[layer_idx][b0:b0 + bsz].copy_(u_r.to(self.dtype))
+            sv = sv.to(self.dtype)
         self.SV[layer_idx][b0:b0 + bsz].copy_(sv.view(bsz, r, kv, D).permute(0, 2, 3, 1))
-        del u, s, v
 
     def register_k_landmark(self, k_landmark, k_landmark_idx, layer_idx):
         n = k_landmark.shape[-2]

@@ -45,6 +45,30 @@ def test_svd_factors(built):
     assert np.array_equal(sha(cache.SV[0]), z["h_cpu_SV"])
 
 
+def test_gram_factorisation_reconstructs_like_svd(built):
+    """svd_mode='gram' (K^T K eigendecomposition) is not bit-comparable with torch.svd
+    (column signs, different algorithm): compared through what the decode path consumes - the rank-r reconstruction
+    U.SV of the pre-RoPE keys - against the reference-pinned factors, in f32 from the stored bf16 factors."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    case, cache, _, inp = built
+    c = G.CASES[case]
+    g = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                          sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], svd_mode="gram")
+    g.get_svd(inp["k_pre"], 0)
+    kv, D = cache.num_key_value_heads, cache.head_dim
+    k = inp["k_pre"].float()                                                  # [1, kv, L, D]
+    def recon(cc):
+        return torch.einsum("blr,bhdr->bhld", cc.U[0].float(), cc.SV[0].float())
+    ref, got = recon(cache), recon(g)
+    scale = k.pow(2).mean().sqrt()
+    e_ref = (ref - k).pow(2).mean().sqrt() / scale                            # truncation + bf16 storage error
+    e_got = (got - k).pow(2).mean().sqrt() / scale
+    assert e_got <= e_ref * 1.02 + 1e-3, (float(e_got), float(e_ref))
+    assert (got - ref).pow(2).mean().sqrt() / scale < 0.02
+    with pytest.raises(ValueError):
+        ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", svd_mode="qr")
+
+
 def test_landmarks_and_initial_selection(built):
     _, cache, z, _ = built
     assert np.array_equal(cache.k_landmark_idx[0].numpy(), z["cpu_lm_idx"])
