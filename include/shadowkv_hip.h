@@ -267,6 +267,16 @@ SKV_EXPORT int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const v
                              int K, int q_heads, int kv_heads, int head_dim, long long cos_sin_stride,
                              long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
 
+/* ---- part 4: prefill-side state builder ---------------------------------------- */
+
+/* Chunk means (landmark candidates) and per-chunk minimum cosine similarity (outlier score) of the post-RoPE keys,
+ * one pass over K: /root/reference/models/kv_cache.py:854 (key_states_roped_ctx.mean(dim=-2)) and :859-868
+ * (cosine_similarity(...).min(dim=-1).values), with torch's bf16 rounding points.
+ * k [blocks][rows >= chunks*chunk_size][head_dim] bf16, block_stride in elements; means [blocks][chunks][head_dim]
+ * bf16, min_cos [blocks][chunks] bf16.  chunk_size must be 8, head_dim 128. */
+SKV_EXPORT int skv_chunk_stats(const void* k, long long block_stride, int blocks, int chunks, int chunk_size,
+                    int head_dim, void* means, void* min_cos, skv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,15 @@ def sparse_attention(q, k, v, kv_len, scale):
     lib().oracle_sparse_attention(_p(q), _p(k), _p(v), _p(out), _p(out32), _i(bs), _i(qh), _i(kvh), _i(d),
                                   _i(kv_len), _l(rows), _f(scale))
     return out, out32
+
+
+def chunk_stats(k_ctx):
+    """k_ctx bf16 [blocks, rows, 128] (rows = chunks * 8) -> (means bf16 [blocks, chunks, 128], min_cos bf16
+    [blocks, chunks]): the chunk means and the per-chunk minimum cosine similarity of kv_cache.py:854-868."""
+    blocks, rows, d = k_ctx.shape
+    assert d == 128 and rows % 8 == 0
+    chunks = rows // 8
+    means = torch.empty(blocks, chunks, 128, dtype=torch.bfloat16)
+    mc = torch.empty(blocks, chunks, dtype=torch.bfloat16)
+    lib().oracle_chunk_stats(_p(k_ctx), _l(rows * 128), _i(blocks), _i(chunks), _p(means), _p(mc))
+    return means, mc

@@ -540,3 +540,67 @@ ORACLE_API void oracle_sparse_attention(const uint16_t *q, const uint16_t *k, co
             free(sc);
         }
 }
+
+/* ------------------------------------------------------------------------- */
+/* f1: prefill-side chunk statistics (models/kv_cache.py:854-868)            */
+/* ------------------------------------------------------------------------- */
+/* k [blocks][>= chunks*8 rows][128] bf16 (block_stride elements between blocks), chunk = 8 consecutive rows.
+ *   means[b][c][:]  = key_states_roped_ctx.mean(dim=-2)                       (kv_cache.py:854)
+ *   min_cos[b][c]   = cosine_similarity(mean.expand, chunk rows, dim=-1).min(dim=-1).values   (kv_cache.py:859-868)
+ * with torch's bf16 tensor semantics, one rounding per ATen op (checked against torch on CPU in
+ * tests/test_oracle_golden.py):  mean = bf16(sum_f32(rows) / 8);  ||x|| = bf16(sqrt(sum_f32(x^2))) clamped below at
+ * bf16(1e-8);  xn = bf16(x / ||x||);  p = bf16(xn1 * xn2);  cos = bf16(sum_f32(p)).
+ * The f32 summation ORDER is this file's contract (torch's differs between CPU and GPU builds and is not
+ * specified): 128-wide sums = lane l of 16 sums its 8 contiguous elements sequentially from 0, then a balanced
+ * tree over the 16 lane partials in natural order (as score_dot above); the 8-row sum of the mean is
+ * ((r0+r4)+(r1+r5)) + ((r2+r6)+(r3+r7)).  Sums of 8 bf16 values are exact in f32 unless their exponents spread over
+ * more than 16 bits, so the means agree with torch bit for bit in practice; cos values can differ from torch's by
+ * one bf16 ulp on a small fraction of rows. */
+static float sum128_lane_tree(const float *x) {
+    float part[16];
+    for (int l = 0; l < 16; ++l) {
+        float s = 0.f;
+        for (int j = 0; j < 8; ++j) s = s + x[8 * l + j];
+        part[l] = s;
+    }
+    for (int w = 1; w < 16; w <<= 1)
+        for (int l = 0; l < 16; l += 2 * w) part[l] = part[l] + part[l + w];
+    return part[0];
+}
+
+ORACLE_API void oracle_chunk_stats(const uint16_t *k, long block_stride, int blocks, int chunks,
+                                   uint16_t *means, uint16_t *min_cos) {
+    const float eps = bf2f(f2bf(1e-8f));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < blocks; ++b)
+        for (int c = 0; c < chunks; ++c) {
+            const uint16_t *rows = k + (size_t)b * block_stride + (size_t)c * 8 * 128;
+            uint16_t *mo = means + ((size_t)b * chunks + c) * 128;
+            float m[128], tmp[128], q1[128];
+            for (int d = 0; d < 128; ++d) {
+                float a[4];
+                for (int r = 0; r < 4; ++r) a[r] = bf2f(rows[r * 128 + d]) + bf2f(rows[(r + 4) * 128 + d]);
+                float s = (a[0] + a[1]) + (a[2] + a[3]);
+                mo[d] = f2bf(s * 0.125f);
+                m[d] = bf2f(mo[d]);
+                tmp[d] = m[d] * m[d];
+            }
+            float n1 = bf2f(f2bf(sqrtf(sum128_lane_tree(tmp))));
+            if (n1 < eps) n1 = eps;
+            for (int d = 0; d < 128; ++d) q1[d] = bf2f(f2bf(m[d] / n1));
+            float best = INFINITY;
+            for (int r = 0; r < 8; ++r) {
+                float x[128];
+                for (int d = 0; d < 128; ++d) {
+                    x[d] = bf2f(rows[r * 128 + d]);
+                    tmp[d] = x[d] * x[d];
+                }
+                float n2 = bf2f(f2bf(sqrtf(sum128_lane_tree(tmp))));
+                if (n2 < eps) n2 = eps;
+                for (int d = 0; d < 128; ++d) tmp[d] = bf2f(f2bf(q1[d] * bf2f(f2bf(x[d] / n2))));
+                float cs = bf2f(f2bf(sum128_lane_tree(tmp)));
+                if (cs < best) best = cs;
+            }
+            min_cos[(size_t)b * chunks + c] = f2bf(best + 0.0f);   /* +0: one sign for a zero minimum */
+        }
+}

@@ -269,9 +269,15 @@ class ShadowKVCache_CPU:
 
         k_ctx = key_states_roped[:, :, :ctx].view(bsz, kv, self.chunks, C, D)
         v_ctx = new_v_cache[:, :, :ctx].view(bsz, kv, self.chunks, C, D)
-        means = k_ctx.mean(dim=-2)                                             # landmark candidates
-        cos_sim = torch.nn.functional.cosine_similarity(means.unsqueeze(3).expand(-1, -1, -1, C, -1), k_ctx, dim=-1)
-        outlier_idx = cos_sim.min(dim=-1).values.topk(self.outlier_chunk, largest=False).indices
+        if key_states_roped.is_cuda and C == 8 and D == 128 and key_states_roped.dtype == torch.bfloat16 \
+                and key_states_roped.is_contiguous():
+            # one native pass over K (skv_chunk_stats): landmark candidates + outlier score
+            means, min_cos = tensor_op.chunk_stats(key_states_roped[:, :, :ctx], C)
+        else:                                                                  # host mirror (CPU tests), other shapes
+            means = k_ctx.mean(dim=-2)                                         # landmark candidates
+            min_cos = torch.nn.functional.cosine_similarity(means.unsqueeze(3).expand(-1, -1, -1, C, -1), k_ctx,
+                                                            dim=-1).min(dim=-1).values
+        outlier_idx = min_cos.topk(self.outlier_chunk, largest=False).indices
         sel = outlier_idx[..., None, None].expand(-1, -1, -1, C, D)
         n_out = self.outlier_chunk * C
         self.sparse_start = self.prefill_local + n_out

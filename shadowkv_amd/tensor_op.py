@@ -246,6 +246,20 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     return out
 
 
+def chunk_stats(k_ctx, chunk_size=8):
+    """k_ctx bf16 [bs, kv, rows, D] (row-contiguous view, rows >= chunks*chunk_size used from row 0), D = 128 ->
+    (means [bs, kv, chunks, D], min_cos [bs, kv, chunks]): kv_cache.py:854-868 in one native pass over K."""
+    bs, kv, rows, D = k_ctx.shape
+    if k_ctx.stride(3) != 1 or k_ctx.stride(2) != D or k_ctx.stride(0) != kv * k_ctx.stride(1):
+        raise ValueError("k_ctx must be a row-contiguous [bs, kv, rows, D] view")
+    chunks = rows // chunk_size
+    means = torch.empty(bs, kv, chunks, D, dtype=k_ctx.dtype, device=k_ctx.device)
+    min_cos = torch.empty(bs, kv, chunks, dtype=k_ctx.dtype, device=k_ctx.device)
+    check(lib().skv_chunk_stats(ptr(k_ctx), k_ctx.stride(1), bs * kv, chunks, chunk_size, D, ptr(means), ptr(min_cos),
+                                current_stream_handle()), "chunk_stats")
+    return means, min_cos
+
+
 def minference_prefill_kernel(*args, **kwargs):
     raise NotImplementedError("MInference sparse prefill is outside the decode hot path (SURVEY.md section 2a)")
 

@@ -1,0 +1,118 @@
+"""GPU: the prefill-side state builder kernel skv_chunk_stats (chunk means + per-chunk minimum cosine similarity,
+/root/reference/models/kv_cache.py:854-868) through the C ABI against oracle_chunk_stats (bit-exact), and
+ShadowKVCache_CPU.prefill_kv_cache built on the GPU (native pass) against the same cache built on the CPU with the
+reference-pinned torch ops."""
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as G
+import oracle
+from util import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(blocks, chunks, seed, extra_rows=0):
+    g = torch.Generator().manual_seed(seed)
+    k = torch.randn(blocks, chunks * 8 + extra_rows, 128, generator=g)
+    k *= torch.exp(torch.randn(blocks, chunks * 8 + extra_rows, 1, generator=g))       # row norms spread
+    k = k.bfloat16()
+    if chunks >= 3:
+        k[0, 0:8] = 0                                   # an all-zero chunk (norm clamp)
+        k[-1, 8:16] = k[-1, 8:9]                        # identical rows: cos == 1 up to rounding
+        k[0, 16:24] *= 1e-3
+    return k
+
+
+@pytest.mark.parametrize("blocks,chunks,extra", [(1, 1, 0), (3, 5, 0), (8, 1021, 0), (2, 4100, 40), (16, 257, 8)])
+def test_chunk_stats_bit_exact_against_oracle(blocks, chunks, extra):
+    from shadowkv_amd import tensor_op
+    k = _case(blocks, chunks, 11 * blocks + chunks, extra)                            # [blocks, rows, 128]
+    want_m, want_c = oracle.chunk_stats(k[:, :chunks * 8].contiguous())
+    kd = k.to(DEV).view(1, blocks, -1, 128)
+    got_m, got_c = tensor_op.chunk_stats(kd[:, :, :chunks * 8], 8)                     # a view: block stride > used rows
+    assert_bits_equal(got_m.cpu().view(blocks, chunks, 128), want_m)
+    assert_bits_equal(got_c.cpu().view(blocks, chunks), want_c)
+
+
+def test_chunk_stats_full_size_properties():
+    """Headline shape (8 kv heads x 15,608 chunks of a 124,928-token context): size-independent properties.
+    Chunks of 8 identical rows: mean == the row bit for bit and the score is cos(x, x) ~ 1; permuting the rows of a
+    chunk changes neither its mean nor its minimum (the 8-row sum is exact in f32 for same-scale bf16 rows)."""
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(9)
+    chunks = 15608
+    k = torch.randn(1, 8, chunks * 8, 128, device=DEV, generator=g).bfloat16()
+    k[:, :, : 8 * 100] = k[:, :, : 8 * 100].view(1, 8, 100, 8, 128)[:, :, :, :1].expand(-1, -1, -1, 8, -1).reshape(1, 8, 800, 128)
+    m, c = tensor_op.chunk_stats(k, 8)
+    assert torch.equal(m[:, :, :100].view(torch.int16), k[:, :, 0:800:8].view(torch.int16))
+    assert (c[:, :, :100].float() - 1).abs().max() <= 2 ** -6
+    perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device=DEV)
+    kp = k.view(1, 8, chunks, 8, 128)[:, :, :, perm].reshape(1, 8, chunks * 8, 128).contiguous()
+    m2, c2 = tensor_op.chunk_stats(kp, 8)
+    assert torch.equal(m.view(torch.int16), m2.view(torch.int16))
+    assert torch.equal(c.view(torch.int16), c2.view(torch.int16))
+    # against torch's own ops on the GPU on a slice (torch's f32 summation order differs: one-ulp flips allowed)
+    ks = k[:, :, : 8 * 2048].view(1, 8, 2048, 8, 128)
+    tm = ks.mean(dim=-2)
+    tc = torch.nn.functional.cosine_similarity(tm.unsqueeze(3).expand(-1, -1, -1, 8, -1), ks, dim=-1).min(-1).values
+    assert torch.equal(tm.view(torch.int16), m[:, :, :2048].view(torch.int16))
+    d = (tc.float() - c[:, :, :2048].float()).abs()
+    assert (d == 0).float().mean() > 0.995 and d.max() <= 2 ** -8
+
+
+def test_chunk_stats_rejects_unsupported_shapes():
+    from shadowkv_amd import _lib
+    k = torch.zeros(1, 64, 128, device=DEV, dtype=torch.bfloat16)
+    m = torch.zeros(1, 8, 128, device=DEV, dtype=torch.bfloat16)
+    c = torch.zeros(1, 8, device=DEV, dtype=torch.bfloat16)
+    L = _lib.lib()
+    assert L.skv_chunk_stats(_lib.ptr(k), 64 * 128, 1, 4, 16, 128, _lib.ptr(m), _lib.ptr(c), 0) != 0
+    assert L.skv_chunk_stats(_lib.ptr(k), 64 * 128, 1, 8, 8, 64, _lib.ptr(m), _lib.ptr(c), 0) != 0
+    assert L.skv_chunk_stats(0, 64 * 128, 1, 8, 8, 128, _lib.ptr(m), _lib.ptr(c), 0) != 0
+    assert L.skv_chunk_stats(_lib.ptr(k), 64 * 128, 1, 0, 8, 128, _lib.ptr(m), _lib.ptr(c), 0) == 0    # empty: no-op
+
+
+@pytest.mark.parametrize("case", list(G.CASES))
+def test_prefill_state_built_on_gpu_equals_cpu_build(case):
+    """prefill_kv_cache with the native pass (GPU) against the torch-op host mirror (CPU), which the golden fixtures pin
+    to the reference bit for bit: landmarks, landmark ids, initial selection, buffers."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    c, inp = G.CASES[case], G.make_inputs(case)
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+    caches = {}
+    for dev in ("cpu", DEV):
+        cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=dev, dtype=torch.bfloat16,
+                                  sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+        cache.U = torch.zeros(1, 1, c["L"], c["rank"], dtype=torch.bfloat16, device=dev)   # factorisation not under test
+        cache.SV = torch.zeros(1, 1, c["kv_heads"], 128, c["rank"], dtype=torch.bfloat16, device=dev)
+        cache.prefill_kv_cache(inp["v"].to(dev), 0, k_roped.to(dev), inp["q_last"].to(dev))
+        caches[dev] = cache
+    if DEV.startswith("cuda"):
+        torch.cuda.synchronize()
+    a, b = caches["cpu"], caches[DEV]
+    kv, C, D = c["kv_heads"], c["chunk"], 128
+    # outlier pick = topk(smallest) of the scores: identical unless the boundary value is tied (torch.topk's tie
+    # order is unspecified and differs between its CPU and GPU kernels)
+    _, mc = oracle.chunk_stats(k_roped[0, :, : a.chunks * C].contiguous())
+    for h in range(kv):
+        srt = mc[h].float().sort().values
+        tied = a.outlier_chunk > 0 and srt[a.outlier_chunk - 1] == srt[a.outlier_chunk]
+        if not tied:
+            assert torch.equal(a.k_landmark_idx[0][0, h], b.k_landmark_idx[0][0, h].cpu()), h
+            assert_bits_equal(b.k_landmark[0][0, h].cpu(), a.k_landmark[0][0, h])
+    # local rows and outlier region: exact copies of the source rows, whichever chunks were picked
+    pl, ss, se = b.prefill_local, b.sparse_start, b.sparse_end
+    assert (pl, ss, se) == (a.prefill_local, a.sparse_start, a.sparse_end)
+    assert_bits_equal(b.k_cache_buffer[0][:, :, :pl].cpu(), a.k_cache_buffer[0][:, :, :pl])
+    assert_bits_equal(b.v_cache_buffer[0][:, :, :pl].cpu(), a.v_cache_buffer[0][:, :, :pl])
+    # sparse region: slot i holds chunk position_ids[i] (the invariant decode relies on), K and V
+    for h in range(kv):
+        ids = b.position_ids[0][0, h].cpu()
+        assert ids.min() >= 0 and ids.max() < b.chunks and ids.unique().numel() == ids.numel()
+        want_v = inp["v"][0, h].view(-1, C, D)[ids].reshape(-1, D)
+        want_k = k_roped[0, h].view(-1, C, D)[ids].reshape(-1, D)
+        assert_bits_equal(b.v_cache_buffer[0][0, h, ss:se].cpu(), want_v)
+        assert_bits_equal(b.k_cache_buffer[0][0, h, ss:se].cpu(), want_k)

@@ -69,6 +69,38 @@ def test_gram_factorisation_reconstructs_like_svd(built):
         ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", svd_mode="qr")
 
 
+def test_oracle_chunk_stats_against_torch_and_reference_fixture(built):
+    """oracle_chunk_stats (the checker of the native state-builder kernel skv_chunk_stats) restates kv_cache.py:854-868
+    with torch's bf16 rounding points: against torch's own ops on the fixture's keys, and - through the outlier pick -
+    against the landmark indices the reference produced."""
+    import oracle
+    case, cache, z, inp = built
+    c = G.CASES[case]
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+    C, D, ctx = cache.chunk_size, cache.head_dim, cache.chunks * cache.chunk_size
+    kv = cache.num_key_value_heads
+    k_ctx = k_roped[:, :, :ctx].contiguous()
+    means, min_cos = oracle.chunk_stats(k_ctx.view(kv, ctx, D))
+    kc = k_ctx.view(1, kv, cache.chunks, C, D)
+    t_means = kc.mean(dim=-2)
+    t_cos = torch.nn.functional.cosine_similarity(t_means.unsqueeze(3).expand(-1, -1, -1, C, -1), kc, dim=-1).min(-1).values
+    assert torch.equal(means.view_as(t_means), t_means)
+    diff = (min_cos.view_as(t_cos).float() - t_cos.float()).abs()
+    assert (diff == 0).float().mean() >= 0.999 and diff.max() <= 2 ** -8      # at most one bf16 ulp (values <= 1)
+    # outlier pick from the oracle's scores == the chunks missing from the reference's landmark index list
+    ref_idx = torch.from_numpy(z["cpu_lm_idx"]).view(kv, -1)
+    for h in range(kv):
+        kept = set(ref_idx[h].tolist())
+        ref_out = sorted(set(range(cache.chunks)) - kept)
+        if not ref_out:                                  # budget < 1024: the reference keeps no outlier chunks
+            continue
+        mine = min_cos[h].float()
+        thr = mine[ref_out].max()
+        assert (mine <= thr).sum() >= len(ref_out) > (mine < thr).sum()
+        # every chunk strictly below the threshold value is an outlier in the reference too (ties at thr may differ)
+        assert set(torch.nonzero(mine < thr).flatten().tolist()) <= set(ref_out)
+
+
 def test_landmarks_and_initial_selection(built):
     _, cache, z, _ = built
     assert np.array_equal(cache.k_landmark_idx[0].numpy(), z["cpu_lm_idx"])
