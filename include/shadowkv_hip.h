@@ -267,6 +267,29 @@ SKV_EXPORT int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const v
                              int K, int q_heads, int kv_heads, int head_dim, long long cos_sin_stride,
                              long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
 
+/* ---- part 3b: in-place chunk layout (MI355X-first variant of parts 1-2) ---------------------------------------- */
+
+/* skv_select_chunks with an IN-PLACE resident set: chunks selected again keep their slot, the misses (ascending chunk
+ * id) take the slots of the evicted chunks (ascending slot).  Same selected SET as skv_select_chunks /
+ * /root/reference/models/kv_cache.py:1006-1057 (and the same `selected_out`), a different slot ORDER: no resident row
+ * ever moves, so the d2d compaction of reorder_keys_and_compute_offsets + gather_copy_d2d_with_offsets
+ * (/root/reference/kernels/map.cuh:754-796, gather_copy.cu) has nothing to do.  Attention is order-independent.
+ *   cached_pos_ids [blocks][S] in/out: id per slot (only the freed slots are rewritten)
+ *   cnts [blocks] out: hits;   for r in [0, S - cnt): miss_ids[b][cnt + r] = id, dst_slots[b][cnt + r] = slot */
+SKV_EXPORT int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_t* landmark_idx,
+                              int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
+                              void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
+                              int n_landmarks, int select_sets, float alpha, skv_stream_t stream);
+
+/* skv_fetch_kv for the in-place layout: K rows of the misses rebuilt (U[idx].SV^T + RoPE) and V chunks of the misses
+ * fetched from the pinned host table, each written to slot dst_slots[.] of the sparse region; one launch. */
+SKV_EXPORT int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                         const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host, void* v_cache,
+                         int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets, int chunk_size,
+                         long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                         long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                         skv_stream_t stream);
+
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 
 /* Chunk means (landmark candidates) and per-chunk minimum cosine similarity (outlier score) of the post-RoPE keys,

@@ -14,8 +14,8 @@ int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void
 int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
                                   int score_stride, int B, int G, int N, hipStream_t st);
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
-                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
-                            hipStream_t st);
+                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
+                            int B, int N, int S, hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, const int32_t* offsets, const int32_t* cnts,
                          unsigned int* signals, long long host_len_elems, long long dev_stride_elems,
                          long long dev_off_elems, int B, int S, hipStream_t st);
@@ -25,8 +25,8 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
-                       const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
-                       long long v_stride, long long v_off, hipStream_t st);
+                       const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp,
+                       long long v_host_stride, long long v_stride, long long v_off, hipStream_t st);
 int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
                           const int32_t* cnts, long long stride_elems, long long off_elems, int B, int S,
                           hipStream_t st);
@@ -107,7 +107,7 @@ int skv_reorder_keys_and_compute_offsets(int64_t* cached_pos_ids, const int64_t*
                                          int32_t* cnts, int batch_size, int heads, int map_size,
                                          skv_stream_t stream) {
     if (!cached_pos_ids || !cur_pos_ids || !offsets || !cnts || batch_size * heads < 1) return SKV_ERR_ARG;
-    return finish(skv_launch_topk_reorder(nullptr, 0, nullptr, cur_pos_ids, cached_pos_ids, offsets, cnts, nullptr,
+    return finish(skv_launch_topk_reorder(nullptr, 0, nullptr, cur_pos_ids, cached_pos_ids, offsets, cnts, nullptr, nullptr,
                                           batch_size * heads, 0, map_size, (hipStream_t)stream));
 }
 
@@ -150,7 +150,7 @@ int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const v
                                      seq_len, embed_dim, rank, sparse_budget / chunk_size, chunk_size, 0,
                                      (long long)heads * sparse_budget * embed_dim,
                                      (long long)sparse_budget * embed_dim, embed_dim, 0, 0, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
+                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
 }
 
 #define SKV_ROPE_PUSH_ARGS                                                                                       \
@@ -245,7 +245,24 @@ int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landm
                                        n_landmarks, st);
     if (rc != SKV_OK) return rc;
     return finish(skv_launch_topk_reorder(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
-                                          selected_out, blocks, n_landmarks, select_sets, st));
+                                          selected_out, nullptr, blocks, n_landmarks, select_sets, st));
+}
+
+int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_t* landmark_idx,
+                              int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
+                              void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
+                              int n_landmarks, int select_sets, float alpha, skv_stream_t stream) {
+    if (!q || !landmarks || !cached_pos_ids || !miss_ids || !dst_slots || !cnts || !workspace) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st);
+    if (rc != SKV_OK) return rc;
+    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
+                                       n_landmarks, st);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_topk_reorder(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
+                                          selected_out, dst_slots, blocks, n_landmarks, select_sets, st));
 }
 
 int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
@@ -275,7 +292,7 @@ int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const i
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len,
                                      head_dim, rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b,
                                      cache_stride_h, cache_stride_s, sparse_start, rope_mode, hit_temp, hit_offsets,
-                                     nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
+                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
 }
 
 int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
@@ -289,9 +306,24 @@ int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
-                                     cache_stride_s, sparse_start, rope_mode, k_temp, offsets, v_host, v_cache, v_temp,
+                                     cache_stride_s, sparse_start, rope_mode, k_temp, offsets, nullptr, v_host, v_cache, v_temp,
                                      host_block_stride, cache_stride_h, (long long)sparse_start * head_dim,
                                      (hipStream_t)stream));
+}
+
+int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                         const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host, void* v_cache,
+                         int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets, int chunk_size,
+                         long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                         long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                         skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache) return SKV_ERR_ARG;
+    if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
+    return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
+                                     v_cache, nullptr, host_block_stride, cache_stride_h,
+                                     (long long)sparse_start * head_dim, (hipStream_t)stream));
 }
 
 int skv_stage_hit_chunks(void* k_cache, void* k_temp, void* v_cache, void* v_temp, const int32_t* offsets,

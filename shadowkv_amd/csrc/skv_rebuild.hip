@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     long long out_stride_b, long long out_stride_h, long long out_stride_s, int out_row0,
     const bf16_t* __restrict__ hit_temp, // nullable: [bs*heads][S][C*128] moved hit chunks staged by skv_stage_hits
     const int32_t* __restrict__ hit_offsets /* [bs*heads][S] */,
+    // in-place layout (skv_select_chunks_inplace): non-null -> virtual slot j in [cnt, S) is the (j-cnt)-th miss, its
+    // chunk id comes from `ids` (the int32 offsets array) and its rows land in slot dst_slots[j]; hits never move
+    const int32_t* __restrict__ dst_slots /* [bs*heads][S] nullable */,
     // optional second role (blocks blockIdx.x >= rebuild_tiles): land the V chunks of this (batch, head) -
     // moved hits from v_temp, misses from the pinned host table - so "K rebuild || V fetch" is ONE launch with no
     // stream fork/join around it.  Rebuild tiles come first in dispatch order (short, few), landing blocks fill
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
             if (i < S) {
                 const int off = hit_offsets[(size_t)bh2 * S + i];
                 if (i < cnt2) {
-                    if (off != i) {
+                    if (!dst_slots && off != i) {
                         lact[k] = true;
                         lv[k] = v_temp[((long long)bh2 * S + i) * 128 + unit];
                     }
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = blk * 8 + k * 2 + rsub;
-            if (lact[k]) v_buf[(long long)bh2 * v_stride_u128 + v_off_u128 + (long long)i * 128 + unit] = lv[k];
+            if (lact[k]) {
+                const int di = dst_slots ? dst_slots[(size_t)bh2 * S + i] : i;
+                v_buf[(long long)bh2 * v_stride_u128 + v_off_u128 + (long long)di * 128 + unit] = lv[k];
+            }
         }
         return;
     }
@@ -204,7 +210,8 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
         if (!evalid[it]) continue;
         const int u = tid + it * 256;
         const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
-        bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h + (size_t)(out_row0 + i) * out_stride_s;
+        const int di = dst_slots ? dst_slots[(size_t)bh * S + i / C] * C + i % C : i;
+        bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h + (size_t)(out_row0 + di) * out_stride_s;
         if (MODE == 0) {
             *reinterpret_cast<u32x4*>(orow + 8 * c) = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
         } else if (MODE == 1) {
@@ -245,7 +252,7 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
-                       const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
+                       const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
                        long long v_stride, long long v_off, hipStream_t st) {
     if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
     if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
@@ -258,14 +265,14 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
     const size_t smem = RB_D * RB_SV_PITCH + RB_ROWS * RB_OUT_PITCH;
     int land_blocks = 0;
     if (v_buf) {
-        if (!v_host || !v_temp || !hit_offsets || (v_host_stride % 8) || (v_stride % 8) || (v_off % 8)) return SKV_ERR_ARG;
+        if (!v_host || (!v_temp && !dst_slots) || !hit_offsets || (v_host_stride % 8) || (v_stride % 8) || (v_off % 8)) return SKV_ERR_ARG;
         land_blocks = (S + 7) / 8;
     }
     dim3 grid(tiles + land_blocks, bs * heads), block(256);
 #define SKV_RB(M, K)                                                                                               \
     hipLaunchKernelGGL((skv_rebuild_kernel<M, K>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,     \
                        (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, ids64, cs_stride,    \
-                       out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets, tiles,    \
+                       out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets, dst_slots, tiles, \
                        (const u32x4*)v_host, (u32x4*)v_buf, (const u32x4*)v_temp, v_host_stride / 8, v_stride / 8, v_off / 8)
 #define SKV_RB_K(M)                 \
     switch (R / 32) {               \

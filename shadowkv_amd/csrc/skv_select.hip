@@ -334,6 +334,10 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     int32_t* __restrict__ offsets,         // [B][S] out
     int32_t* __restrict__ cnts,            // [B] out
     int64_t* __restrict__ sel_out,         // [B][S] nullable: ids selected this step, ascending slot
+    int32_t* __restrict__ dst_slots,       // [B][S] nullable.  Non-null = IN-PLACE layout: resident (hit) chunks keep
+                                           // their slots, the misses (ascending id) take the freed slots (ascending):
+                                           // cached[slot] = id is rewritten only there, offsets[cnt + r] = id and
+                                           // dst_slots[cnt + r] = slot of the r-th miss; nothing is written for hits
     int N, int score_stride, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_cur = smem;            // [SP]
@@ -504,6 +508,8 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         s_out[5] = miss_incl;
     }
     if (is_miss) s_miss[miss_incl - 1] = my_key;
+    int* s_free = s_hvals;  // the hash values are dead after the classification: r-th free slot (ascending)
+    if (dst_slots && tid < S && !is_hit_slot) s_free[tid - hit_incl] = tid;   // free slots among 0..tid: tid+1-hit_incl
     __syncthreads();
     const int cnt = s_out[4], nm = s_out[5];
     TOPK_STAMP(10);
@@ -529,6 +535,16 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     __syncthreads();
     TOPK_STAMP(11);
     // ---- write out
+    if (dst_slots) {
+        if (tid < nm) {
+            const int key = s_miss[tid], r = s_rank[tid], slot = s_free[r];
+            cached[(size_t)b * S + slot] = (long long)key;
+            offsets[(size_t)b * S + cnt + r] = key;
+            dst_slots[(size_t)b * S + cnt + r] = slot;
+        }
+        if (tid == 0) cnts[b] = cnt;
+        return;
+    }
     if (is_hit_slot) {
         int o = hit_incl - 1;
         cached[(size_t)b * S + o] = (long long)s_byslot[tid];
@@ -601,8 +617,8 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
 }
 
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
-                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int B, int N, int S,
-                            hipStream_t st) {
+                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
+                            int B, int N, int S, hipStream_t st) {
     if (S < 1 || S > SKV_SEL_THREADS) return SKV_ERR_UNSUPPORTED;
     if (score != nullptr && (N < S || score_stride < N || (score_stride % 8))) return SKV_ERR_ARG;
     const int SP = next_pow2(S);
@@ -620,12 +636,12 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
             attr_bytes = 150 * 1024;
         }
         hipLaunchKernelGGL(skv_topk_reorder_kernel<true>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
-                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, N, score_stride, S, H,
-                           SP);
+                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, N,
+                           score_stride, S, H, SP);
     } else {
         hipLaunchKernelGGL(skv_topk_reorder_kernel<false>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
-                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, N, score_stride, S, H,
-                           SP);
+                           (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, N,
+                           score_stride, S, H, SP);
     }
     return SKV_OK;
 }

@@ -161,6 +161,7 @@ class ShadowKVCache_CPU:
         self._temp_k = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
         self._temp_v = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
         self._staged_layer = -1
+        self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
         self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -380,6 +381,40 @@ class ShadowKVCache_CPU:
                                  self.rank, self.select_sets, self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0),
                                  kbuf.stride(1), kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2,
                                  vhost.stride(1), current_stream_handle()), "fetch_kv")
+
+    # ------------------------------------------------------------------ decode, in-place layout (MI355X-first)
+    def select_fetch_inplace(self, layer_idx, query_states, cos_sin_cache):
+        """get_retrieval_position_ids + get_value_cache + get_key_cache of one layer with an IN-PLACE resident set:
+        chunks selected again keep their slot, the misses take the freed slots, so no resident row moves (the
+        reference compacts the hits to the front every step: kv_cache.py:1044-1057, gather_copy_d2d_with_offsets).
+        Same selected set, same rows in the sparse region - in a different slot order, which attention does not see.
+        4 launches (score, normalize, top-k/diff, rebuild||fetch) instead of 5; position_ids[layer_idx] stays the
+        slot -> chunk map (invariant: slot i holds chunk position_ids[i])."""
+        if query_states.shape[-2] != 1:
+            raise ValueError("decode-time selection expects q_len == 1")
+        self.incoming_q_len = 1
+        lm = self.k_landmark[layer_idx]
+        if self._select_ws is None:
+            self.H2D()
+        if self._dst_slots is None:
+            self._dst_slots = torch.zeros_like(self.offsets)
+        q = query_states if query_states.is_contiguous() else query_states.contiguous()
+        L, st = lib(), current_stream_handle()
+        check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
+                                          ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
+                                          ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
+                                          self.num_key_value_groups, lm.shape[-2], self.select_sets,
+                                          1.0 / math.sqrt(128), st), "select_chunks_inplace")
+        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        vhost = self.v_cache_cpu[layer_idx]
+        U, SV = self.U[layer_idx], self.SV[layer_idx]
+        width = cos_sin_cache.shape[-1]
+        check(L.skv_fetch_kv_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
+                                     ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), U.shape[0],
+                                     self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
+                                     self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
+                                     kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
+              "fetch_kv_inplace")
 
     def note_kv_appended(self, incoming=1):
         """Bookkeeping half of update_kv_cache for callers that wrote the new K / V rows themselves

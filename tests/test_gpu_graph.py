@@ -7,21 +7,22 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _make(seed=5, glm=False):
+def _make(seed=5, glm=False, layout="reference"):
     from shadowkv_amd import llama
     cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
                             num_attention_heads=8, num_key_value_heads=2, vocab_size=2000,
                             qkv_bias=glm, rope_style="glm" if glm else "neox")
     m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
-                        seed=seed)
+                        seed=seed, chunk_layout=layout)
     llama.build_synthetic_context(m, 4608, seed=77)
     return m, llama
 
 
+@pytest.mark.parametrize("layout", ["reference", "inplace"])
 @pytest.mark.parametrize("use_walk", [False, True])
-def test_graph_equals_eager(use_walk):
+def test_graph_equals_eager(use_walk, layout):
     steps = 6
-    m1, llama = _make()
+    m1, llama = _make(layout=layout)
     table = llama.make_walk_table(m1, steps, seed=3) if use_walk else None
     tok0 = torch.tensor([[17]], device=DEV)
     # eager reference
@@ -32,7 +33,7 @@ def test_graph_equals_eager(use_walk):
         toks1.append(int(t))
     torch.cuda.synchronize()
     # graph
-    m2, _ = _make()
+    m2, _ = _make(layout=layout)
     dec = llama.GraphDecoder(m2, temperature=0.0, walk_table=table)
     dec.token.copy_(tok0)
     warm = dec.capture(warmup=2)
@@ -275,3 +276,20 @@ def test_two_level_topk_matches_torch_topk():
         vr, _ = torch.topk(x, 50, dim=-1)
         assert torch.equal(v, vr)
         assert torch.equal(x.gather(-1, i), v)
+
+
+def test_inplace_layout_decodes_the_same_tokens_as_reference_layout():
+    """Fused decode with chunk_layout='inplace' against 'reference' on the same model / context / walk: the same
+    chunk sets every step (sorted position_ids equal) and the same greedy tokens (attention differs only in the order
+    of its f32 sums, far below the gaps between logits of this model)."""
+    steps = 6
+    m1, llama = _make(layout="reference")
+    m2, _ = _make(layout="inplace")
+    table = llama.make_walk_table(m1, steps, seed=3)
+    t1 = t2 = torch.tensor([[17]], device=DEV)
+    for i in range(steps):
+        t1 = m1.decode_step(t1, temperature=0.0, q_table=table[i])
+        t2 = m2.decode_step(t2, temperature=0.0, q_table=table[i])
+        assert int(t1) == int(t2), i
+        assert torch.equal(m1.kv_cache.position_ids.sort(dim=-1).values, m2.kv_cache.position_ids.sort(dim=-1).values), i
+    assert not torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)   # the slot order does differ

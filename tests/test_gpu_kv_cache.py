@@ -146,3 +146,45 @@ def test_fetch_kv_single_launch_equals_two_calls(case):
         assert torch.equal(ca.position_ids, cb.position_ids)
         assert_bits_equal(ca.k_cache_buffer, cb.k_cache_buffer, f"step {t}: K")
         assert_bits_equal(ca.v_cache_buffer, cb.v_cache_buffer, f"step {t}: V")
+
+
+@pytest.mark.parametrize("case", ["llama_small", "llama_cpu_b1024", "glm_small"])
+def test_inplace_layout_same_set_same_rows_no_hit_moves(case):
+    """select_fetch_inplace against the reference-order path (get_retrieval_position_ids + fetch_kv) from the same
+    starting state over several steps: the same chunk SET per head and the same hit count every step; slot i of the
+    in-place cache holds chunk position_ids[i] with exactly the K / V rows the reference-order cache holds for that
+    chunk; a chunk selected again never changes slot; attention over both layouts agrees to summation order."""
+    from shadowkv_amd import tensor_op
+    ref, c, inp = _build(case)
+    inp_cache, _, _ = _build(case)
+    kv, D, C, S = c["kv_heads"], c["head_dim"], c["chunk"], ref.select_sets
+    cs_dev = inp["cos_sin"].to(DEV)
+    ss, se = ref.sparse_start, ref.sparse_end
+    assert torch.equal(ref.position_ids, inp_cache.position_ids)
+    for t in range(inp["q_steps"].shape[0]):
+        qd = inp["q_steps"][t].to(DEV)
+        before = inp_cache.position_ids[0][0].clone()
+        ids = ref.get_retrieval_position_ids(layer_idx=0, query_states=qd)
+        ref.fetch_kv(0, ids, cs_dev)
+        inp_cache.select_fetch_inplace(0, qd, cs_dev)
+        torch.cuda.synchronize()
+        a, b = ref.position_ids[0][0], inp_cache.position_ids[0][0]
+        assert torch.equal(a.sort(dim=-1).values, b.sort(dim=-1).values), t
+        assert torch.equal(ref.cnts, inp_cache.cnts)
+        for h in range(kv):
+            keep = before[h] == b[h]                                      # slots whose chunk survived
+            assert int(keep.sum()) == int(inp_cache.cnts[h]), (t, h)
+            # misses: ascending ids into ascending freed slots
+            new_ids = b[h][~keep]
+            assert torch.equal(new_ids, new_ids.sort().values)
+            # row contents per chunk id, both layouts
+            order_a, order_b = a[h].argsort(), b[h].argsort()
+            for buf_a, buf_b in ((ref.k_cache_buffer, inp_cache.k_cache_buffer), (ref.v_cache_buffer, inp_cache.v_cache_buffer)):
+                ra = buf_a[0][0, h, ss:se].view(S, C * D)[order_a]
+                rb = buf_b[0][0, h, ss:se].view(S, C * D)[order_b]
+                assert_bits_equal(rb, ra, f"step {t} head {h}")
+            want_v = inp["v"][0, h].view(-1, C, D)[b[h].cpu()].reshape(-1, D)
+            assert_bits_equal(inp_cache.v_cache_buffer[0][0, h, ss:se], want_v)
+        o_ref = tensor_op.sparse_attention_decode(qd, ref.k_cache_buffer[0][:, :, :se], ref.v_cache_buffer[0][:, :, :se])
+        o_inp = tensor_op.sparse_attention_decode(qd, inp_cache.k_cache_buffer[0][:, :, :se], inp_cache.v_cache_buffer[0][:, :, :se])
+        assert torch.allclose(o_ref.float(), o_inp.float(), rtol=2 ** -7, atol=2e-3)
