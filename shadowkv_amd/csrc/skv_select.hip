@@ -351,6 +351,8 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     int* s_out = s_wave + 32;     // [8]
     bf16_t* s_score = reinterpret_cast<bf16_t*>(s_out + 8);  // [score_stride] when STAGE_LDS
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the resident id of this thread's slot is requested now: its (cold) latency overlaps the selection passes
+    const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
 
     if (score != nullptr) {
         const bf16_t* gsc = score + (size_t)b * score_stride;
@@ -425,28 +427,35 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         TOPK_STAMP(6);
         gt_before -= c_gt;
         eq_before -= c_eq;
-        for (int i = v0; i < v1; ++i) {
-            const u32x4 v = svec[i];
+        // one candidate: exact rank among the selected (ties at the threshold -> lowest slot first)
+#define SKV_ASSIGN(VAL, J, IDEXPR)                                         \
+    do {                                                                   \
+        int pos = -1;                                                      \
+        if ((VAL) > thr) {                                                 \
+            pos = gt_before + min(eq_before, need_eq);                     \
+            ++gt_before;                                                   \
+        } else if ((VAL) == thr) {                                         \
+            if (eq_before < need_eq) pos = gt_before + eq_before;          \
+            ++eq_before;                                                   \
+        }                                                                  \
+        if (pos >= 0) {                                                    \
+            const long long id = (IDEXPR);                                 \
+            s_cur[pos] = (int)id;                                          \
+            if (sel_out) sel_out[(size_t)b * S + pos] = id;                \
+        }                                                                  \
+    } while (0)
+        {
+            for (int i = v0; i < v1; ++i) {
+                const u32x4 v = svec[i];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
-                const int j = i * 8 + e;
-                if (j >= N) continue;
-                int pos = -1;
-                if (val > thr) {
-                    pos = gt_before + min(eq_before, need_eq);
-                    ++gt_before;
-                } else if (val == thr) {
-                    if (eq_before < need_eq) pos = gt_before + eq_before;
-                    ++eq_before;
-                }
-                if (pos >= 0) {
-                    long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
-                    s_cur[pos] = (int)id;
-                    if (sel_out) sel_out[(size_t)b * S + pos] = id;
+                for (int e = 0; e < 8; ++e) {
+                    const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                    const int j = i * 8 + e;
+                    if (j < N) SKV_ASSIGN(val, j, lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j);
                 }
             }
         }
+#undef SKV_ASSIGN
     } else {
         if (tid < S) s_cur[tid] = (int)cur_in[(size_t)b * S + tid];
     }
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     }
     __syncthreads();
     if (tid < S) {
-        int key = (int)cached[(size_t)b * S + tid];
+        int key = my_cached;
         if (key >= 0) {
             unsigned pos = (unsigned)key & (unsigned)(H - 1);
             for (int probe = 0; probe < H; ++probe) {

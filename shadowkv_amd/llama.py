@@ -397,14 +397,15 @@ class GraphDecoder:
 
     @staticmethod
     def _topk(x, k, parts=64):
-        """torch.topk(x, k, dim=-1) as two levels of short-slice top-k: top-k of each of `parts` slices, then top-k of
-        the parts*k survivors (the global top-k is a subset of them).  Not only cheaper than one radix select over the
-        whole vocabulary: PyTorch's multi-block top-k with more than one slice faults under hipGraph replay on this
-        ROCm build (tools/topk_graph_probe.py, pure PyTorch) - short slices take its single-block path."""
+        """torch.topk(x, k, dim=-1).  For bs > 1 over a large vocabulary: two levels of short-slice top-k (top-k of
+        each of `parts` slices, then top-k of the parts*k survivors - the global top-k is a subset of them), because
+        PyTorch's multi-block top-k with more than one slice faults under hipGraph replay on this ROCm build
+        (tools/topk_graph_probe.py, pure PyTorch); short slices take its single-block path.  One slice (bs == 1)
+        replays fine and is the cheaper call there."""
         bs, V = x.shape
-        if V % parts or V // parts < k or V < 16384:
-            if bs == 1 or V < 16384:
-                return torch.topk(x, k, dim=-1)
+        if bs == 1 or V < 16384:                 # one slice (multi-block path, fine under replay) / short slices
+            return torch.topk(x, k, dim=-1)
+        if V % parts or V // parts < k:
             rows = [torch.topk(x[b:b + 1], k, dim=-1) for b in range(bs)]     # one slice per call
             return torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
         w = V // parts

@@ -5,7 +5,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
-int main() {
+int main(int argc, char** argv) {
+    const bool inplace = argc > 1 && !strcmp(argv[1], "inplace");
     const int B = 8, N = 15560, S = 256, stride = (N + 7) & ~7;
     std::vector<uint16_t> sc((size_t)B * stride);
     std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * S);
@@ -13,13 +14,28 @@ int main() {
     for (auto& v : sc) { float p = 6.4e-5f * (0.6f + 0.8f * rand() / RAND_MAX); uint32_t u; memcpy(&u, &p, 4); v = u >> 16; }
     for (int b = 0; b < B; ++b) for (int j = 0; j < N; ++j) lm[(size_t)b * N + j] = j + j / 300;
     for (int b = 0; b < B; ++b) for (int j = 0; j < S; ++j) cached[(size_t)b * S + j] = (j * 61) % N;
-    uint16_t* dsc; int64_t *dlm, *dc, *dsel; int32_t *doff, *dcnt;
+    uint16_t* dsc; int64_t *dlm, *dc, *dsel; int32_t *doff, *dcnt, *dslot;
     hipMalloc(&dsc, sc.size() * 2); hipMalloc(&dlm, lm.size() * 8); hipMalloc(&dc, cached.size() * 8); hipMalloc(&dsel, cached.size() * 8);
-    hipMalloc(&doff, B * S * 4); hipMalloc(&dcnt, B * 4);
+    hipMalloc(&doff, B * S * 4); hipMalloc(&dcnt, B * 4); hipMalloc(&dslot, B * S * 4);
     hipMemcpy(dsc, sc.data(), sc.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dlm, lm.data(), lm.size() * 8, hipMemcpyHostToDevice);
-    for (int it = 0; it < 3; ++it) {
+    char* flush; const size_t flush_bytes = (size_t)640 << 20; hipMalloc(&flush, flush_bytes);   // > L2 + MALL
+    const bool cold = argc > 2 && !strcmp(argv[2], "cold");
+    for (int it = 0; it < 4; ++it) {
         hipMemcpy(dc, cached.data(), cached.size() * 8, hipMemcpyHostToDevice);
-        int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, B, N, S, 0);
+        if (cold) { hipMemset(flush, it, flush_bytes); hipDeviceSynchronize(); }   // evicts data AND the kernel's code
+        if (argc > 3 && !strcmp(argv[3], "warmcode")) {   // same kernel on OTHER buffers first: code warm, data cold
+            static uint16_t* dsc2 = nullptr; static int64_t *dlm2, *dc2; static int32_t *doff2, *dcnt2;
+            if (!dsc2) {
+                hipMalloc(&dsc2, sc.size() * 2); hipMalloc(&dlm2, lm.size() * 8); hipMalloc(&dc2, cached.size() * 8);
+                hipMalloc(&doff2, B * S * 4); hipMalloc(&dcnt2, B * 4);
+                hipMemcpy(dsc2, sc.data(), sc.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dlm2, lm.data(), lm.size() * 8, hipMemcpyHostToDevice);
+                hipMemcpy(dc2, cached.data(), cached.size() * 8, hipMemcpyHostToDevice);
+                hipMemset(flush, 9, flush_bytes); hipDeviceSynchronize();
+            }
+            skv_launch_topk_reorder(dsc2, stride, dlm2, nullptr, dc2, doff2, dcnt2, nullptr, nullptr, B, N, S, 0);
+            hipDeviceSynchronize();
+        }
+        int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
         hipDeviceSynchronize();
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
         const char* names[] = {"stage+hist1", "select1", "zero", "hist2", "select2", "count", "scan", "assign+gather", "hash init+insert", "lookup", "scan2", "ranksort", "write"};
@@ -29,7 +45,7 @@ int main() {
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int it = 0; it < 50; ++it) skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, B, N, S, 0);
+    for (int it = 0; it < 50; ++it) skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("back-to-back launches: %.2f us per launch (event time, includes launch boundary)\n", ms * 1e3 / 50);
