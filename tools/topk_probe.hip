@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSKV_TOPK_STAMPS -I shadowkv_amd/csrc tools/topk_probe.hip -o /tmp/topk_probe
 #include "../shadowkv_amd/csrc/skv_select.hip"
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
@@ -11,7 +12,17 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> sc((size_t)B * stride);
     std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * S);
     srand(3);
-    for (auto& v : sc) { float p = 6.4e-5f * (0.6f + 0.8f * rand() / RAND_MAX); uint32_t u; memcpy(&u, &p, 4); v = u >> 16; }
+    // scores shaped like the decode step's softmax probabilities: log-normal, sigma from argv (0 = flat +-40 %)
+    const float sigma = argc > 4 ? atof(argv[4]) : 0.f;
+    for (auto& v : sc) {
+        float p;
+        if (sigma == 0.f) p = 6.4e-5f * (0.6f + 0.8f * rand() / RAND_MAX);
+        else {
+            float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
+            p = 6.4e-5f * expf(sigma * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2));
+        }
+        uint32_t u; memcpy(&u, &p, 4); v = u >> 16;
+    }
     for (int b = 0; b < B; ++b) for (int j = 0; j < N; ++j) lm[(size_t)b * N + j] = j + j / 300;
     for (int b = 0; b < B; ++b) for (int j = 0; j < S; ++j) cached[(size_t)b * S + j] = (j * 61) % N;
     uint16_t* dsc; int64_t *dlm, *dc, *dsel; int32_t *doff, *dcnt, *dslot;
