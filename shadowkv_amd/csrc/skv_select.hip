@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
 //   4. diff against the resident set through an LDS hash set, hits ordered by old slot with a
 //      counting pass, misses ordered by chunk id with a rank sort (S^2/1024 compares per thread).
 // ---------------------------------------------------------------------------------------
+#ifndef SKV_SEL_THREADS
 #define SKV_SEL_THREADS 1024
+#endif
 
 // Phase stamps for tools/topk_probe.hip (diagnostic build only, -DSKV_TOPK_STAMPS; no stamp executes in the
 // shipped library).  100 MHz wall clock, written by thread 0 of workgroup 0 to a buffer nothing else reads.
@@ -333,6 +335,29 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the resident id of this thread's slot is requested now: its (cold) latency overlaps the selection passes
     const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
+    // hash set of the resident ids (key -> lowest slot): initialised here, filled while the scores are in flight
+    for (int i = tid; i < H; i += SKV_SEL_THREADS) {
+        s_hkeys[i] = -1;
+        s_hvals[i] = 0x7fffffff;
+    }
+    for (int i = tid; i < SP; i += SKV_SEL_THREADS) {
+        s_byslot[i] = -1;
+        s_rank[i] = 0;
+    }
+    auto insert_resident = [&]() {
+        if (tid < S && my_cached >= 0) {
+            unsigned pos = (unsigned)my_cached & (unsigned)(H - 1);
+            for (int probe = 0; probe < H; ++probe) {
+                int prev = atomicCAS(&s_hkeys[pos], -1, my_cached);
+                if (prev == -1 || prev == my_cached) {
+                    atomicMin(&s_hvals[pos], tid);
+                    break;
+                }
+                pos = (pos + 1) & (unsigned)(H - 1);
+            }
+        }
+    };
+    int my_key = -1;   // id selected into position tid (tid < S)
 
     if (score != nullptr) {
         const bf16_t* gsc = score + (size_t)b * score_stride;
@@ -367,6 +392,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
                 }
             }
         }
+        insert_resident();   // (hash arrays were initialised before the barrier above)
         __syncthreads();
         if (tid < 256) {   // fold the 32 copies; thread t starts at copy t so the 64 lanes of a wave read 32 banks
             int t = 0;
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         gt_before -= c_gt;
         eq_before -= c_eq;
         // one candidate: exact rank among the selected (ties at the threshold -> lowest slot first)
-#define SKV_ASSIGN(VAL, J, IDEXPR)                                         \
+#define SKV_ASSIGN(VAL, J)                                                 \
     do {                                                                   \
         int pos = -1;                                                      \
         if ((VAL) > thr) {                                                 \
@@ -429,59 +455,38 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
             if (eq_before < need_eq) pos = gt_before + eq_before;          \
             ++eq_before;                                                   \
         }                                                                  \
-        if (pos >= 0) {                                                    \
-            const long long id = (IDEXPR);                                 \
-            s_cur[pos] = (int)id;                                          \
-            if (sel_out) sel_out[(size_t)b * S + pos] = id;                \
-        }                                                                  \
+        if (pos >= 0) s_cur[pos] = (J);                                    \
     } while (0)
-        {
-            for (int i = v0; i < v1; ++i) {
-                const u32x4 v = svec[i];
+        for (int i = v0; i < v1; ++i) {
+            const u32x4 v = svec[i];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
-                    const int j = i * 8 + e;
-                    if (j < N) SKV_ASSIGN(val, j, lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
+                const int j = i * 8 + e;
+                if (j < N) SKV_ASSIGN(val, j);
             }
         }
 #undef SKV_ASSIGN
+        __syncthreads();
+        // slot -> chunk id for the S selected slots: one parallel gather (not inside the serial loop above)
+        if (tid < S) {
+            const int j = s_cur[tid];
+            const long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
+            my_key = (int)id;
+            if (sel_out) sel_out[(size_t)b * S + tid] = id;
+        }
     } else {
-        if (tid < S) s_cur[tid] = (int)cur_in[(size_t)b * S + tid];
+        if (tid < S) my_key = (int)cur_in[(size_t)b * S + tid];
+        __syncthreads();     // hash arrays initialised
+        insert_resident();
+        __syncthreads();
     }
 
     TOPK_STAMP(7);
-    // ---- hash set of resident ids: key -> lowest slot
-    for (int i = tid; i < H; i += SKV_SEL_THREADS) {
-        s_hkeys[i] = -1;
-        s_hvals[i] = 0x7fffffff;
-    }
-    for (int i = tid; i < SP; i += SKV_SEL_THREADS) {
-        s_byslot[i] = -1;
-        s_rank[i] = 0;
-    }
-    __syncthreads();
-    if (tid < S) {
-        int key = my_cached;
-        if (key >= 0) {
-            unsigned pos = (unsigned)key & (unsigned)(H - 1);
-            for (int probe = 0; probe < H; ++probe) {
-                int prev = atomicCAS(&s_hkeys[pos], -1, key);
-                if (prev == -1 || prev == key) {
-                    atomicMin(&s_hvals[pos], tid);
-                    break;
-                }
-                pos = (pos + 1) & (unsigned)(H - 1);
-            }
-        }
-    }
-    __syncthreads();
     TOPK_STAMP(8);
     // ---- classify the new ids
-    int my_key = -1, my_slot = -1;
+    int my_slot = -1;
     if (tid < S) {
-        my_key = s_cur[tid];
         if (my_key >= 0) {
             unsigned pos = (unsigned)my_key & (unsigned)(H - 1);
             for (int probe = 0; probe < H; ++probe) {

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
         int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
         hipDeviceSynchronize();
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
-        const char* names[] = {"stage+hist1", "select1", "zero", "hist2", "select2", "count", "scan", "assign+gather", "hash init+insert", "lookup", "scan2", "ranksort", "write"};
+        const char* names[] = {"stage+hist1(+hash build)", "select1+zero", "hist2", "select2", "count", "scan", "assign+gather", "-", "lookup", "scan2", "sorted-vote", "write"};
         printf("run %d rc=%d total %.2f us :", it, rc, (st[12] - st[0]) / 100.0);
         for (int i = 0; i < 12; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
         printf("\n");
