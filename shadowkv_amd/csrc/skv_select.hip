@@ -246,31 +246,37 @@ __device__ unsigned long long g_topk_stamps[24];
 #define TOPK_STAMP(i)
 #endif
 
+// Inclusive integer scans on DPP (no LDS crossbar round trips): within rows of 16 lanes row_shr 1/2/4/8, then
+// row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2-3 (the GFX9 wave64 scan).  Lanes without a source read
+// `old` = 0.
+__device__ __forceinline__ int row16_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v = row16_scan_incl(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // inclusive scan of two ints per thread over the 1024-thread workgroup (same barriers for both)
 __device__ __forceinline__ void block_scan_incl2(int& a, int& b, int* s_wave /*[32]*/, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int na = __shfl_up(a, o, 64), nb = __shfl_up(b, o, 64);
-        if (lane >= o) {
-            a += na;
-            b += nb;
-        }
-    }
+    a = wave_scan_incl(a);
+    b = wave_scan_incl(b);
     if (lane == 63) {
         s_wave[wave] = a;
         s_wave[16 + wave] = b;
     }
     __syncthreads();
-    if (tid < 32) {
-        int w = s_wave[tid];
-        const int l16 = tid & 15;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            int n = __shfl_up(w, o, 16);
-            if (l16 >= o) w += n;
-        }
-        s_wave[tid] = w;
+    if (tid < 64) {   // whole wave 0 runs the DPP steps; rows 0 and 1 hold the 16 + 16 wave totals
+        int w = tid < 32 ? s_wave[tid] : 0;
+        w = row16_scan_incl(w);
+        if (tid < 32) s_wave[tid] = w;
     }
     __syncthreads();
     if (wave > 0) {
@@ -289,12 +295,7 @@ __device__ __forceinline__ void select_bin_desc_wave0(const int* hist, int k, in
         c[j] = hist[255 - (4 * lane + j)];
         t += c[j];
     }
-    int incl = t;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int n = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += n;
-    }
+    const int incl = wave_scan_incl(t);
     int run = incl - t;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
