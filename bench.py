@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--layout", default="inplace", choices=["reference", "inplace"],
                     help="slot order of the resident chunk set: the reference's (hits compacted to the front) or "
                          "in place (hits keep their slots; same chunk set, no hit movement)")
+    ap.add_argument("--v-table", default="host", choices=["host", "hbm"],
+                    help="where the chunked V table lives: pinned host memory (the headline configuration, the "
+                         "reference's offload) or HBM (8 GB per sequence; not the headline metric)")
     ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
     ap.add_argument("--walk-step", type=float, default=0.3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,7 +250,8 @@ def main():
     bs = args.batch
     model = llama.DecoderLM(cfg=cfg, batch_size=bs, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
                             chunk_size=8, num_layers=args.layers, seed=1234 + rank,
-                            attn_mode="full" if full else "shadowkv_cpu", chunk_layout=args.layout)
+                            attn_mode="full" if full else "shadowkv_cpu", chunk_layout=args.layout,
+                            v_offload=args.v_table == "host")
     if bs > 1:
         args.no_cpu_baseline = True
     if full:
@@ -354,7 +358,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
-                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}"
+                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
                                    + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
         }

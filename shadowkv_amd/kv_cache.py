@@ -104,7 +104,7 @@ def gram_factorize(k, rank):
 
 class ShadowKVCache_CPU:
     def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
-                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd"):
+                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd", v_offload=True):
         if dtype != torch.bfloat16:
             raise ValueError("ShadowKVCache_CPU supports bfloat16 only (as the reference's kernels do)")
         self.config = config
@@ -132,8 +132,15 @@ class ShadowKVCache_CPU:
 
         L, bs, kv, D, C = self.num_layers, batch_size, self.num_key_value_heads, self.head_dim, chunk_size
         on_gpu = self.device.type == "cuda"
-        self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype,
-                                       pin_memory=on_gpu)
+        # the chunked V table: pinned host memory (the reference's offload, read over PCIe by the fetch kernel) or,
+        # with v_offload=False, HBM (what the reference's GPU-resident ShadowKVCache does, kv_cache.py:155-506: the
+        # same kernels then gather the misses at HBM speed; 8 GB per 122K-token sequence of the 288 GB)
+        self.v_offload = bool(v_offload) or not on_gpu
+        if self.v_offload:
+            self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype,
+                                           pin_memory=on_gpu)
+        else:
+            self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device=self.device, dtype=dtype)
         buf_len = self.sparse_budget + 128 + (self.outlier_chunk + self.local_chunk) * C
         self.k_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)
         self.v_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)

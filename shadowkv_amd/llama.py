@@ -78,7 +78,7 @@ def build_cos_sin_cache(cfg, max_pos, device, dtype):
 class DecoderLM:
     def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
-                 num_layers=None, chunk_layout="reference"):
+                 num_layers=None, chunk_layout="reference", v_offload=True):
         if chunk_layout not in ("reference", "inplace"):
             raise ValueError("chunk_layout must be 'reference' (hits compacted to the front, the reference's slot order) "
                              "or 'inplace' (hits keep their slots, misses take the freed slots)")
@@ -120,7 +120,7 @@ class DecoderLM:
         else:
             self.kv_cache = ShadowKVCache_CPU(_CacheCfg, batch_size=batch_size, max_length=max_length, device=device,
                                               dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size,
-                                              rank=rank)
+                                              rank=rank, v_offload=v_offload)
         self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
 
     def weight_bytes(self):

@@ -188,3 +188,28 @@ def test_inplace_layout_same_set_same_rows_no_hit_moves(case):
         o_ref = tensor_op.sparse_attention_decode(qd, ref.k_cache_buffer[0][:, :, :se], ref.v_cache_buffer[0][:, :, :se])
         o_inp = tensor_op.sparse_attention_decode(qd, inp_cache.k_cache_buffer[0][:, :, :se], inp_cache.v_cache_buffer[0][:, :, :se])
         assert torch.allclose(o_ref.float(), o_inp.float(), rtol=2 ** -7, atol=2e-3)
+
+
+def test_v_table_in_hbm_gives_the_same_cache_bytes():
+    """v_offload=False (V table resident in HBM, like the reference's GPU-only ShadowKVCache) through the same
+    kernels: identical buffers and ids after several steps."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    case = "llama_cpu_b1024"
+    a, c, inp = _build(case)
+    b = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=DEV, dtype=torch.bfloat16,
+                          sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], v_offload=False)
+    assert b.v_cache_cpu.is_cuda and not a.v_cache_cpu.is_cuda
+    b.get_svd(inp["k_pre"].to(DEV), 0)
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0)).to(DEV)
+    b.prefill_kv_cache(inp["v"].to(DEV), 0, k_roped, inp["q_last"].to(DEV))
+    b.H2D()
+    cs_dev = inp["cos_sin"].to(DEV)
+    for t in range(inp["q_steps"].shape[0]):
+        qd = inp["q_steps"][t].to(DEV)
+        for cache in (a, b):
+            ids = cache.get_retrieval_position_ids(layer_idx=0, query_states=qd)
+            cache.fetch_kv(0, ids, cs_dev)
+    torch.cuda.synchronize()
+    assert torch.equal(a.position_ids, b.position_ids)
+    assert_bits_equal(a.v_cache_buffer, b.v_cache_buffer)
+    assert_bits_equal(a.k_cache_buffer, b.k_cache_buffer)
