@@ -14,10 +14,10 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// NORM variant (K == 4096): x is the pre-norm hidden state; every wave recomputes h = x + residual (bf16),
-// the RMS statistics (its 64 lanes x 8 k-steps cover all 4096 elements) and xn = bf16(h * rstd * w_norm) in
-// registers, so "residual add + RMSNorm + projection" is one launch; block 0 / wave 0 stores h (the new
-// residual stream).  Same rounding points as the separate skv_add_rmsnorm launch.
+// NORM variant (K == 4096): x is the pre-norm hidden state; every BLOCK recomputes h = x + residual (bf16), the
+// RMS statistics and xn = bf16(h * rstd * w_norm) cooperatively (256 threads x 16 elements, through LDS), so
+// "residual add + RMSNorm + projection" is one launch; block 0 stores h (the new residual stream).  Same
+// element -> thread mapping and reduction tree as skv_add_rmsnorm_kernel: bit-identical to the separate launch.
 // QKV epilogue (QKV == true, W = fused [q; k; v] projection of ONE token, head_dim 128): the wave's 4 rows are two
 // rotation pairs of one head - NeoX: (t, t+64), (t+1, t+65); GLM: (2t', 2t'+1), (2t'+2, 2t'+3) - so lane 0 can rotate
 // q / k at the token's position and write q to q_out and k / v straight into the cache row: the projection, the
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
         } else rows[r] = unit0 + r;
     }
     const int limit = SILU_PAIR ? I : N;
-    if (unit0 >= limit) return;
+    if (!NORM && unit0 >= limit) return;   // (NORM: every wave takes part in the block-wide prologue first)
     const bf16_t* wp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -77,36 +77,58 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     }
     f32x2 xn[NORM ? 8 : 1][4];
     if (NORM) {
-        u32x4 hx[8];
+        // Block-cooperative prologue: the 256 threads split the 4096 elements exactly like skv_add_rmsnorm_kernel
+        // (thread t owns 16-B vectors t and t + 256, same per-thread order, same wave tree, same (s0+s1)+(s2+s3)),
+        // so h, rstd and xn are bit-identical to the separate launch; xn goes through LDS and every wave picks up
+        // its k-step slices (vector 64 u + lane for step u).  One read of x / residual / w_norm per BLOCK.
+        __shared__ u32x4 s_xn[512];
+        __shared__ float s_ss[4];
+        const int tid = threadIdx.x;
+        u32x4 hx[2];
         float ss = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            u32x4 a = *reinterpret_cast<const u32x4*>(xp + (size_t)u * 512);
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * 256;
+            u32x4 a = reinterpret_cast<const u32x4*>(x)[v];
             if (residual) {
-                u32x4 c = *reinterpret_cast<const u32x4*>(residual + 8 * lane + (size_t)u * 512);
+                u32x4 c = reinterpret_cast<const u32x4*>(residual)[v];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = pack_bf2(bf_lo(a[j]) + bf_lo(c[j]), bf_hi(a[j]) + bf_hi(c[j]));
             }
-            hx[u] = a;
+            hx[it] = a;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ss = __builtin_fmaf(bf_lo(a[j]), bf_lo(a[j]), ss);
                 ss = __builtin_fmaf(bf_hi(a[j]), bf_hi(a[j]), ss);
             }
         }
-        if (h_out && blockIdx.x == 0 && wave == 0) {
+        if (h_out && blockIdx.x == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<u32x4*>(h_out + 8 * lane + (size_t)u * 512) = hx[u];
+            for (int it = 0; it < 2; ++it) reinterpret_cast<u32x4*>(h_out)[tid + it * 256] = hx[it];
         }
         ss = wave_tree_sum(ss);
-        const float rstd = 1.0f / sqrtf(ss / (float)K + eps);
+        if (lane == 0) s_ss[wave] = ss;
+        __syncthreads();
+        const float tot = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+        const float rstd = 1.0f / sqrtf(tot / (float)K + eps);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            u32x4 g = *reinterpret_cast<const u32x4*>(w_norm + 8 * lane + (size_t)u * 512);
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * 256;
+            u32x4 g = reinterpret_cast<const u32x4*>(w_norm)[v];
+            u32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xn[u][j] = (f32x2){bfr(bf_lo(hx[u][j]) * rstd * bf_lo(g[j])), bfr(bf_hi(hx[u][j]) * rstd * bf_hi(g[j]))};
+                o[j] = pack_bf2(bf_lo(hx[it][j]) * rstd * bf_lo(g[j]), bf_hi(hx[it][j]) * rstd * bf_hi(g[j]));
+            s_xn[v] = o;
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x4 o = s_xn[u * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xn[u][j] = (f32x2){bf_lo(o[j]), bf_hi(o[j])};
+        }
+        if (unit0 >= limit) return;
     }
     f32x2 acc[R][4];
 #pragma unroll

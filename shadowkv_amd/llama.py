@@ -194,11 +194,11 @@ class DecoderLM:
     @torch.inference_mode()
     def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
         """Same computation as inference() for q_len == 1, with the small ops fused and the step's
-        scalars in device memory (graph-capturable): 12 launches per layer instead of ~40 (11 when bs == 1).
+        scalars in device memory (graph-capturable): 10 launches per layer at bs == 1 (in-place layout) instead of ~40.
           token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
           kv_len / kv_len_dev: rows attended (= row_idx + 1), q_table: optional [L, bs, Hq, 1, D] synthetic queries.
-        Per layer: [add+RMSNorm+QKV GEMV] -> split/RoPE/cache-push -> select (3) -> stage hits -> [land K + rebuild
-        || land V + PCIe fetch, one launch] -> attention (2) -> O GEMV -> [add+RMSNorm+gate/up GEMV+SiLU*mul] -> down GEMV."""
+        Per layer: [add+RMSNorm+QKV GEMV+split/RoPE/cache-push] -> select (3) -> (reference layout: stage hits) ->
+        [K rebuild || V fetch, one launch] -> attention (2) -> O GEMV -> [add+RMSNorm+gate/up GEMV+SiLU*mul] -> down GEMV."""
         c = self.kv_cache
         x = F.embedding(token, self.embed_tokens)
         residual = None
@@ -219,12 +219,12 @@ class DecoderLM:
                 c.fetch_kv(l, ids, self.cos_sin_cache)
             attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
-            # (the norm prologue is NOT fused into this GEMV: measured 47 us fused vs 5 + 37 us separate -
-            #  7168 waves each redoing the 4096-element statistics cost more than the launch they save)
-            residual, hs = tensor_op.add_rmsnorm(o, residual, layer.post_attention_layernorm_weight,
-                                                 layer.post_attention_layernorm_variance_epsilon)
-            x = tensor_op.linear_decode(tensor_op.linear_decode(hs, layer.gate_up_proj, fuse_silu_mul=True),
-                                        layer.down_proj)
+            # residual add + RMSNorm ride in the gate/up GEMV's block-cooperative prologue (one launch when bs == 1
+            # and hidden == 4096, bit-identical to add_rmsnorm + GEMV; otherwise norm_linear_decode splits it)
+            residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
+                                                         layer.post_attention_layernorm_variance_epsilon,
+                                                         layer.gate_up_proj, fuse_silu_mul=True)
+            x = tensor_op.linear_decode(act, layer.down_proj)
         _, logits = tensor_op.norm_linear_decode(x, residual, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
         return logits.float()
 
