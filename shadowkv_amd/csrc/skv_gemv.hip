@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     for (int r = 0; r < R; ++r) {
         if (SILU_PAIR) rows[r] = (r & 1) ? I + unit0 + r / 2 : unit0 + r / 2;  // (gate, up) pairs
         else if (QKV && !qe.glm) {
-            // unit0 = 4 * wave index; wave index w -> head w / 32, t0 = 2 * (w % 32); rows t0, t0+64, t0+1, t0+65
-            const int w = unit0 / 4, head = w / 32, t0 = 2 * (w % 32);
+            // unit0 = R * wave index; a wave owns R/2 rotation pairs (t, t+64) of one head: 128/R waves per head,
+            // rows t0, t0+64, t0+1, t0+65, ...
+            const int w = unit0 / R, head = w / (128 / R), t0 = (R / 2) * (w % (128 / R));
             rows[r] = head * 128 + t0 + (r >> 1) + ((r & 1) ? 64 : 0);
         } else rows[r] = unit0 + r;
     }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     }
     if (QKV) {
         if (lane == 0 && unit0 < N) {
-            const int head = unit0 / 128;                       // 4 rows of one head (unit0 % 4 == 0)
+            const int head = unit0 / 128;                       // the wave's R rows belong to one head
             float o[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) o[r] = bfr(bias ? bfr(tot[r]) + bf2f(bias[rows[r]]) : tot[r]);  // the projection output is bf16
@@ -258,8 +259,8 @@ static int launch_gemv(const void* W, const void* x, const void* bias, void* y, 
     if (qkv) {
         if (fuse_silu_mul || N != (qe.Hq + 2 * qe.Hkv) * 128) return SKV_ERR_ARG;
         const int grid = (N + 15) / 16;
-        if (norm)
-            hipLaunchKernelGGL((skv_gemv_kernel<4, false, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)W,
+        if (norm)   // one rotation pair per wave: 3,072 waves for N = 6144 (two pairs per wave: 200.4 -> 202.3 tok/s)
+            hipLaunchKernelGGL((skv_gemv_kernel<2, false, true, true>), dim3((N + 7) / 8), dim3(256), 0, st, (const bf16_t*)W,
                                (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)nullptr, N, K, 0, (const bf16_t*)residual,
                                (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe);
         else
