@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
     for (int i = 0; i < SKV_SCORE_ITERS; ++i) {
         int row = row0 + i * 4;
         row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
-        x[i] = *reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub);
+        x[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub));
     }
     const int my_g = row16_owner<G>(lane);
     const bool publish = row16_publisher<G>(lane);
@@ -197,6 +197,11 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
     const int b = blockIdx.y, t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_m[G], s_inv[G];
+    // the column's G logits do not depend on the statistics: request them first (one memory round trip, not two)
+    const int col = t * SKV_TILE + tid;
+    bf16_t dreg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) dreg[g] = col < N ? D[((size_t)b * G + g) * N + col] : (bf16_t)0;
     for (int g = wave; g < G; g += 4) {
         float mx, inv;
         softmax_finalize_wave(part_max + (size_t)b * T * G + g, part_sum + (size_t)b * T * G + g, T, G, lane, mx, inv);
@@ -206,13 +211,12 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
         }
     }
     __syncthreads();
-    const int col = t * SKV_TILE + tid;
     if (col >= N) return;
     bf16_t best = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const size_t o = ((size_t)b * G + g) * N + col;
-        bf16_t p = f2bf(spec_exp(bf2f(D[o]) - s_m[g]) * s_inv[g]);
+        bf16_t p = f2bf(spec_exp(bf2f(dreg[g]) - s_m[g]) * s_inv[g]);
         if (P) P[o] = p;
         best = p > best ? p : best;  // p >= 0: unsigned order == float order
     }
