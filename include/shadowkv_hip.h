@@ -242,7 +242,7 @@ SKV_EXPORT int skv_silu_and_mul(const void* x, void* out, int rows, int inter, s
 /* y[n] = W[n][:] . x (+ bias[n]) for ONE token: W [N][K] bf16 row-major, x [K], y [N] bf16, f32 accumulation
  * (the decode-time F.linear calls of /root/reference/models/llama.py:380,407,415,424 at q_len == 1, bs == 1).
  * fuse_silu_mul != 0: W = [gate; up] (N = 2I rows), y [I] = silu(gate.x) * (up.x)  (llama.py:415-421).
- * K must be a multiple of 512. */
+ * K must be a multiple of 8 and >= 512. */
 SKV_EXPORT int skv_gemv_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                   skv_stream_t stream);
 

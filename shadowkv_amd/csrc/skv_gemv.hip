@@ -5,6 +5,7 @@
 // Replaces F.linear -> hipBLASLt for M = 1 (at bs = 1 the
 // 15 GB of weights are the largest HBM term of a decode step; the library kernels run them at 2.2-4.7 TB/s).
 //
+// K % 8 == 0, K >= 512 (a partial last 512-element step is handled after the main loop).
 // HBM-bound streaming: a wave owns R weight rows; each wave-instruction reads 1 KiB of a row (64 lanes x
 // 16 B, coalesced), R x 4 row segments are in flight per wave before the first use, x (<= 28 KB) comes from
 // L2.  Per 16 B of weights: 8 conversions + 4 packed FMAs, far below the VALU roof.  Rows are reduced over the
@@ -166,6 +167,20 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
             }
         }
     }
+    if (!NORM) {   // K % 512 != 0 (GLM-4: 13696 = 26 x 512 + 384): the last partial step, lanes below the tail only
+        const int tail_lanes = (K % 512) / 8;
+        if (lane < tail_lanes) {
+            const u32x4 xt = *reinterpret_cast<const u32x4*>(xp + (size_t)ksteps * 512);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const u32x4 wt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)ksteps * 512));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[r][j] = __builtin_elementwise_fma((f32x2){bf_lo(wt[j]), bf_hi(wt[j])},
+                                                          (f32x2){bf_lo(xt[j]), bf_hi(xt[j])}, acc[r][j]);
+            }
+        }
+    }
     float tot[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -250,7 +265,7 @@ static int launch_gemv(const void* W, const void* x, const void* bias, void* y, 
     if (!W || !x || (!y && !qkv) || N < 1) return SKV_ERR_ARG;
     QkvEpilogue qe{};
     if (qkv) qe = *qkv;
-    if (K % 512 || K < 512) return SKV_ERR_UNSUPPORTED;
+    if (K % 8 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
 #define SKV_GEMV(SILU, NORMF, GRID, IARG)                                                                            \
     hipLaunchKernelGGL((skv_gemv_kernel<4, SILU, NORMF, false>), dim3(GRID), dim3(256), 0, st, (const bf16_t*)W,      \

@@ -44,7 +44,7 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False):
     rows or shapes the kernels are not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
     K = x.shape[-1]
     rows = x.numel() // K
-    if rows > MAX_GEMV_ROWS or K % 512 or not x.is_contiguous() or not w.is_contiguous():
+    if rows > MAX_GEMV_ROWS or K % 32 or K < 512 or not x.is_contiguous() or not w.is_contiguous():
         out = F.linear(x, w, bias)
         return silu_and_mul_fused(out) if fuse_silu_mul else out
     N = w.shape[0]

@@ -97,7 +97,7 @@ def test_fused_small_ops_against_torch():
 
 
 @pytest.mark.parametrize("N,K,silu", [(6144, 4096, False), (4096, 14336, False), (28672, 4096, True), (1000, 1024, False),
-                                      (4101, 512, False)])
+                                      (4101, 512, False), (4096, 13696, False), (27392, 4096, True), (1000, 520, False)])
 def test_gemv_against_f32_reference(N, K, silu):
     from shadowkv_amd import tensor_op
     g = torch.Generator(device=DEV).manual_seed(N + K)
