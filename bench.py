@@ -139,7 +139,7 @@ def measure_path_only(model, walk, steps=8):
     return dt * 1e3, hit_rate
 
 
-def cpu_baseline(model, walk, sample_layers=2, sample_steps=2):
+def cpu_baseline(model, walk, sample_layers=4, sample_steps=4):
     """The oracle (CPU restatement, OpenMP) timed on this box's host cores for the ShadowKV path of
     `sample_layers` layers x `sample_steps` tokens, plus torch-CPU bf16 F.linear for one layer's dense
     weights; extrapolated to the full model.  A reported baseline, not a target."""
