@@ -148,6 +148,7 @@ def cpu_baseline(model, walk, sample_layers=4, sample_steps=4):
     kv, G, D, C, S = cache.num_key_value_heads, cache.num_key_value_groups, cache.head_dim, cache.chunk_size, cache.select_sets
     cores = os.cpu_count()
     torch.set_num_threads(cores)
+    sample_layers = min(sample_layers, model.num_layers)
     path_s = 0.0
     for l in range(sample_layers):
         lm = cache.k_landmark[l][0].cpu().contiguous(); lm_idx = cache.k_landmark_idx[l][0].cpu().contiguous()
