@@ -157,6 +157,8 @@ def cpu_baseline(model, walk, sample_layers=4, sample_steps=4):
         pos = cache.position_ids[l][0].cpu().clone()
         kbuf = cache.k_cache_buffer[l].cpu().clone(); vbuf = cache.v_cache_buffer[l].cpu().clone()
         vhost = cache.v_cache_cpu[l][0]
+        if vhost.is_cuda:                      # --v-table hbm
+            vhost = vhost.cpu()
         rows = kbuf.shape[2]
         cs = model.cos_sin_cache.cpu()
         qs = []
