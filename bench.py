@@ -97,7 +97,7 @@ def measure_score_kernel(model, iters=3):
 
 
 def measure_path_only(model, walk, steps=8):
-    """The ShadowKV kernels of one token alone (per layer: select -> stage hits -> K rebuild || V fetch -> attention;
+    """The ShadowKV kernels of one token alone (per layer: select -> [stage hits] -> K rebuild || V fetch -> attention;
     dense layers excluded), captured in a hipGraph like the full step.  Returns (ms per token, chunk hit rate)."""
     from shadowkv_amd import llama, tensor_op
     cache = model.kv_cache
@@ -111,9 +111,12 @@ def measure_path_only(model, walk, steps=8):
         q_all = torch.index_select(table, 0, step_idx)[0]
         for l in range(model.num_layers):
             q = q_all[l]
-            ids = cache.get_retrieval_position_ids(layer_idx=l, query_states=q)
+            if model.chunk_layout == "inplace":
+                cache.select_fetch_inplace(l, q, model.cos_sin_cache)
+            else:
+                ids = cache.get_retrieval_position_ids(layer_idx=l, query_states=q)
+                cache.fetch_kv(l, ids, model.cos_sin_cache)
             hits.add_(cache.cnts.sum())
-            cache.fetch_kv(l, ids, model.cos_sin_cache)
             tensor_op.sparse_attention_decode(q, cache.k_cache_buffer[l], cache.v_cache_buffer[l], kv_len=0,
                                               kv_len_dev=kv_len)
         step_idx.copy_((step_idx + 1) % table.shape[0])
