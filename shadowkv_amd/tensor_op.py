@@ -233,7 +233,7 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
         q = q.contiguous()
     if splits is None:
         splits = max(1, min(32, 256 // max(1, bs * Hkv)))
-    key = (q.device.index, bs, Hq, splits)
+    key = (q.device.index, bs, Hq, splits, current_stream_handle())   # per stream: pipelines may run concurrently
     ws = _attn_ws.get(key)
     if ws is None:
         ws = torch.empty(lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=q.device)
