@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--layout", default="inplace", choices=["reference", "inplace"],
                     help="slot order of the resident chunk set: the reference's (hits compacted to the front) or "
                          "in place (hits keep their slots; same chunk set, no hit movement)")
+    ap.add_argument("--overlap-attention", type=int, default=1, choices=[0, 1],
+                    help="in-place layout: attention over the resident rows runs inside the fetch launch")
     ap.add_argument("--v-table", default="host", choices=["host", "hbm"],
                     help="where the chunked V table lives: pinned host memory (the headline configuration, the "
                          "reference's offload) or HBM (8 GB per sequence; not the headline metric)")
@@ -257,7 +259,7 @@ def main():
     model = llama.DecoderLM(cfg=cfg, batch_size=bs, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
                             chunk_size=8, num_layers=args.layers, seed=1234 + rank,
                             attn_mode="full" if full else "shadowkv_cpu", chunk_layout=args.layout,
-                            v_offload=args.v_table == "host")
+                            v_offload=args.v_table == "host", overlap_attention=bool(args.overlap_attention))
     if bs > 1:
         args.no_cpu_baseline = True
     if full:

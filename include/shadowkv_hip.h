@@ -290,6 +290,27 @@ SKV_EXPORT int skv_fetch_kv_inplace(const void* U, const void* SV, const void* c
                          long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                          skv_stream_t stream);
 
+/* skv_fetch_kv_inplace plus the attention over every row that is NOT a miss slot, in the same launch: those rows are
+ * final before the launch starts, so their split attention pass runs on the CUs the PCIe-bound V fetch leaves idle
+ * (records go to attn_workspace: skv_attn_workspace_bytes(bs, q_heads, attn_splits)).  Follow with
+ * skv_attn_finish_inplace.  Together they compute exactly what skv_fetch_kv_inplace + skv_sparse_attention compute
+ * (flash_attn_with_kvcache at /root/reference/models/base.py:341), with a different order of the f32 sums.
+ * rank 160, chunk_size 8, q_heads / heads in {4, 8}. */
+SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                              const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
+                              void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
+                              int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              int attn_splits, float scale, skv_stream_t stream);
+
+/* Attention over the miss rows (one workgroup per query head) merged with the records of the split pass above;
+ * out [bs][q_heads][head_dim] bf16. */
+SKV_EXPORT int skv_attn_finish_inplace(const void* q, const void* k_cache, const void* v_cache, const void* attn_workspace,
+                            const int32_t* dst_slots, const int32_t* cnts, void* out, int batch_size, int q_heads,
+                            int kv_heads, int select_sets, long long kv_head_stride, int sparse_start, int attn_splits,
+                            float scale, skv_stream_t stream);
+
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 
 /* Chunk means (landmark candidates) and per-chunk minimum cosine similarity (outlier score) of the post-RoPE keys,

@@ -3,6 +3,7 @@
 // skv_attn / skv_rope.  No allocation, no synchronisation: every entry point is graph-capturable.
 #include "../../include/shadowkv_hip.h"
 #include "skv_common.h"
+#include "skv_launch.h"
 
 #include <string.h>
 
@@ -26,7 +27,11 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
                        const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp,
-                       long long v_host_stride, long long v_stride, long long v_off, hipStream_t st);
+                       long long v_host_stride, long long v_stride, long long v_off, hipStream_t st,
+                       const AttnLaunch* attn);
+int skv_launch_attn_finish(const void* q, const void* k, const void* v, const void* ws, const int32_t* dst_slots,
+                           const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, long long kv_stride_h,
+                           int sparse_start, int rec_splits, float scale, hipStream_t st);
 int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
                           const int32_t* cnts, long long stride_elems, long long off_elems, int B, int S,
                           hipStream_t st);
@@ -150,7 +155,7 @@ int skv_batch_gather_gemm(const void* a, const void* b, const void* cos, const v
                                      seq_len, embed_dim, rank, sparse_budget / chunk_size, chunk_size, 0,
                                      (long long)heads * sparse_budget * embed_dim,
                                      (long long)sparse_budget * embed_dim, embed_dim, 0, 0, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
+                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream, nullptr));
 }
 
 #define SKV_ROPE_PUSH_ARGS                                                                                       \
@@ -292,7 +297,7 @@ int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const i
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len,
                                      head_dim, rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b,
                                      cache_stride_h, cache_stride_s, sparse_start, rope_mode, hit_temp, hit_offsets,
-                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream));
+                                     nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream, nullptr));
 }
 
 int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
@@ -308,7 +313,7 @@ int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, const int64
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, k_temp, offsets, nullptr, v_host, v_cache, v_temp,
                                      host_block_stride, cache_stride_h, (long long)sparse_start * head_dim,
-                                     (hipStream_t)stream));
+                                     (hipStream_t)stream, nullptr));
 }
 
 int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
@@ -323,7 +328,36 @@ int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, con
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
                                      v_cache, nullptr, host_block_stride, cache_stride_h,
-                                     (long long)sparse_start * head_dim, (hipStream_t)stream));
+                                     (long long)sparse_start * head_dim, (hipStream_t)stream, nullptr));
+}
+
+int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                              const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
+                              void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
+                              int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              int attn_splits, float scale, skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache || !q ||
+        !attn_workspace)
+        return SKV_ERR_ARG;
+    if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
+    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, q_heads / heads, attn_splits, attn_splits, scale};
+    return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
+                                     v_cache, nullptr, host_block_stride, cache_stride_h,
+                                     (long long)sparse_start * head_dim, (hipStream_t)stream, &al));
+}
+
+int skv_attn_finish_inplace(const void* q, const void* k_cache, const void* v_cache, const void* attn_workspace,
+                            const int32_t* dst_slots, const int32_t* cnts, void* out, int batch_size, int q_heads,
+                            int kv_heads, int select_sets, long long kv_head_stride, int sparse_start, int attn_splits,
+                            float scale, skv_stream_t stream) {
+    if (!q || !k_cache || !v_cache || !attn_workspace || !dst_slots || !cnts || !out) return SKV_ERR_ARG;
+    return finish(skv_launch_attn_finish(q, k_cache, v_cache, attn_workspace, dst_slots, cnts, out, batch_size, q_heads,
+                                         kv_heads, select_sets, kv_head_stride, sparse_start, attn_splits, scale,
+                                         (hipStream_t)stream));
 }
 
 int skv_stage_hit_chunks(void* k_cache, void* k_temp, void* v_cache, void* v_temp, const int32_t* offsets,

@@ -13,11 +13,7 @@
 // HBM-bound: 2 * kv_len * 256 B per (batch, kv head); K/V rows are read exactly once.
 // kv_len may come from device memory (kv_len_dev) so the launch sequence is graph-capturable.
 #include "../../include/shadowkv_hip.h"
-#include "skv_common.h"
-
-#define AT_D 128
-#define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
-#define AT_REC 132     // floats per (head, split) record: acc[128], m, l, 2 pad (16-B aligned rows)
+#include "skv_attn_body.h"
 
 template <int G>
 __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
@@ -27,120 +23,10 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     float* __restrict__ ws,         // [bs*Hkv][G][splits][AT_REC]  (acc[128], m, l)
     const int* __restrict__ kv_len_dev, int kv_len_host, long long kv_stride_h /*elements*/, int Hkv, int splits,
     float scale) {
-    const int bh = blockIdx.y, split = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
-    const int kv_len = kv_len_dev ? *kv_len_dev : kv_len_host;
-    const int per = (kv_len + splits - 1) / splits;
-    const int k0 = split * per, k1 = min(k0 + per, kv_len);
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
-
-    float qf[G][8];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        u32x4 w = *reinterpret_cast<const u32x4*>(q + ((size_t)bh * G + g) * AT_D + 8 * sub);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qf[g][2 * j] = bf_lo(w[j]) * scale;
-            qf[g][2 * j + 1] = bf_hi(w[j]) * scale;
-        }
-    }
-    float m[G], l[G], acc[G][8];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        m[g] = -INFINITY;
-        l[g] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
-    }
-    const bf16_t* kb = k + (size_t)bh * kv_stride_h + 8 * sub;
-    const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
-    // A 16-lane group takes AT_KB keys per iteration (keys grp + 16*i): 2*AT_KB row loads in flight, the scores of
-    // the batch are reduced first, then ONE running-max update / accumulator rescale per batch instead of per key.
-    constexpr int AT_KB = 4;
-    for (int key0 = k0 + grp; key0 < k1; key0 += AT_GROUPS * AT_KB) {
-        u32x4 kr[AT_KB], vr[AT_KB];
-#pragma unroll
-        for (int i = 0; i < AT_KB; ++i) {
-            const int key = key0 + i * AT_GROUPS;
-            const int kc = key < k1 ? key : k1 - 1;          // clamp; masked below
-            kr[i] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * AT_D);
-            vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * AT_D);
-        }
-        float sc[AT_KB][G];
-#pragma unroll
-        for (int i = 0; i < AT_KB; ++i) {
-            float kf[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bf_lo(kr[i][j]);
-                kf[2 * j + 1] = bf_hi(kr[i][j]);
-            }
-            const bool live = key0 + i * AT_GROUPS < k1;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = __builtin_fmaf(qf[g][j], kf[j], s);
-                s = row16_tree_sum(s);
-                sc[i][g] = live ? s : -INFINITY;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float mn = m[g];
-#pragma unroll
-            for (int i = 0; i < AT_KB; ++i) mn = fmaxf(mn, sc[i][g]);
-            const float corr = __expf(m[g] - mn);              // m = -inf on the first batch: exp(-inf) = 0
-            float lsum = l[g] * corr;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
-#pragma unroll
-            for (int i = 0; i < AT_KB; ++i) {
-                const float p = __expf(sc[i][g] - mn);         // masked keys: exp(-inf) = 0
-                lsum += p;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[g][2 * j] = __builtin_fmaf(p, bf_lo(vr[i][j]), acc[g][2 * j]);
-                    acc[g][2 * j + 1] = __builtin_fmaf(p, bf_hi(vr[i][j]), acc[g][2 * j + 1]);
-                }
-            }
-            l[g] = lsum;
-            m[g] = mn;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[g][j];
-        if (sub == 0) {
-            s_part[grp][g][AT_D] = m[g];
-            s_part[grp][g][AT_D + 1] = l[g];
-        }
-    }
-    __syncthreads();
-    // merge the 16 groups: thread handles (g, d) pairs; G*128 outputs + G stats
-    for (int o = tid; o < G * AT_D; o += 256) {
-        const int g = o / AT_D, d = o % AT_D;
-        float M = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
-        float a = 0.f, L = 0.f;
-#pragma unroll
-        for (int r = 0; r < AT_GROUPS; ++r) {
-            float mr = s_part[r][g][AT_D];
-            float w = (mr == -INFINITY) ? 0.f : __expf(mr - M);
-            a = __builtin_fmaf(s_part[r][g][d], w, a);
-            L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
-        }
-        float* dst = ws + (((size_t)bh * G + g) * splits + split) * AT_REC;
-        dst[d] = a;
-        if (d == 0) {
-            dst[AT_D] = M;
-            dst[AT_D + 1] = L;
-        }
-    }
+    const int kv_len = kv_len_dev ? *kv_len_dev : kv_len_host;
+    skv_attn_partial_body<G, false>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
+                                    nullptr, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
@@ -169,6 +55,146 @@ __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __re
         L = __builtin_fmaf(p[AT_D + 1], w, L);
     }
     out[(size_t)bq * AT_D + d] = f2bf(a / L);
+}
+
+// Second half of the overlapped attention (in-place layout): one workgroup per query head attends the MISS rows
+// (the chunks fetched / rebuilt by the launch that also ran the split pass over all other rows), then merges its 16
+// group partials with the `rec_splits` records of that pass and writes the head's output.
+#define FIN_MAX_REC 30   // records of the split pass merged by the finish kernel (30 * 33 16-B vectors <= 1024 threads)
+#define FIN_GROUPS 64   // 16-lane groups per workgroup (1024 threads): ~11 miss rows per group at 33 % misses
+__global__ __launch_bounds__(FIN_GROUPS * 16) void skv_attn_finish_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const float* __restrict__ ws, const int32_t* __restrict__ dst_slots, const int32_t* __restrict__ cnts,
+    bf16_t* __restrict__ out, int G, int S, long long kv_stride_h, int sparse_start, int rec_splits, float scale) {
+    __shared__ int s_slot[1024];
+    __shared__ float s_part[FIN_GROUPS][AT_D + 2];
+    __shared__ __attribute__((aligned(16))) float s_rec[FIN_MAX_REC * AT_REC];
+    const int bq = blockIdx.x, bh = bq / G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
+    // the whole destination list of this head is requested before the hit count is known (no dependent round trip)
+    for (int i = tid; i < S; i += FIN_GROUPS * 16) s_slot[i] = dst_slots[(size_t)bh * S + i];
+    const int cnt = cnts[bh], nm = S - cnt, nkeys = nm * 8;
+    // the records of the split pass are requested now (one 16-B load per thread, all in flight together) and parked
+    // in LDS after the miss-row loop: the merge never waits on global latency
+    const int nvec = rec_splits * (AT_REC / 4);
+    u32x4 rec_reg = {0u, 0u, 0u, 0u};
+    if (tid < nvec) rec_reg = reinterpret_cast<const u32x4*>(ws + (size_t)bq * rec_splits * AT_REC)[tid];
+    float qf[8];
+    {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(q + (size_t)bq * AT_D + 8 * sub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[2 * j] = bf_lo(w[j]) * scale;
+            qf[2 * j + 1] = bf_hi(w[j]) * scale;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const bf16_t* kb = k + (size_t)bh * kv_stride_h + 8 * sub;
+    const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
+    constexpr int KB = 8;   // 16 row loads in flight per lane: the typical miss list (<= 64 * 8 * 2 rows) is two batches
+    for (int kk0 = grp; kk0 < nkeys; kk0 += FIN_GROUPS * KB) {
+        u32x4 kr[KB], vr[KB];
+        bool alive[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int kk = kk0 + i * FIN_GROUPS;
+            alive[i] = kk < nkeys;
+            const int kc = alive[i] ? kk : kk0;                  // kk0 < nkeys: a valid miss row
+            const size_t row = (size_t)sparse_start + (size_t)s_slot[cnt + (kc >> 3)] * 8 + (kc & 7);
+            kr[i] = *reinterpret_cast<const u32x4*>(kb + row * AT_D);
+            vr[i] = *reinterpret_cast<const u32x4*>(vb + row * AT_D);
+        }
+        float sc[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s = __builtin_fmaf(qf[2 * j], bf_lo(kr[i][j]), s);
+                s = __builtin_fmaf(qf[2 * j + 1], bf_hi(kr[i][j]), s);
+            }
+            s = row16_tree_sum(s);
+            sc[i] = alive[i] ? s : -INFINITY;
+        }
+        float mn = m;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) mn = fmaxf(mn, sc[i]);
+        const float corr = __expf(m - mn);
+        float lsum = l * corr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= corr;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const float p = __expf(sc[i] - mn);
+            lsum += p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] = __builtin_fmaf(p, bf_lo(vr[i][j]), acc[2 * j]);
+                acc[2 * j + 1] = __builtin_fmaf(p, bf_hi(vr[i][j]), acc[2 * j + 1]);
+            }
+        }
+        l = lsum;
+        m = mn;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_part[grp][8 * sub + j] = acc[j];
+    if (sub == 0) {
+        s_part[grp][AT_D] = m;
+        s_part[grp][AT_D + 1] = l;
+    }
+    if (tid < nvec) reinterpret_cast<u32x4*>(s_rec)[tid] = rec_reg;
+    __syncthreads();
+    // ---- merge the FIN_GROUPS group partials and the rec_splits records (<= 94 contributions), all threads:
+    // contribution c: c < FIN_GROUPS -> s_part[c], else record c - FIN_GROUPS
+    __shared__ float s_w[FIN_GROUPS + FIN_MAX_REC];       // weight exp(m_c - M) of every contribution
+    __shared__ float s_red[4];                            // per-wave maxima, then per-wave sums of w * l
+    __shared__ float s_a[8][AT_D];
+    const int ncon = FIN_GROUPS + rec_splits;
+    {   // threads 0..127 (waves 0 and 1) hold one contribution each; everybody runs the same barriers
+        const int c = tid;
+        float mc = -INFINITY, lc = 0.f;
+        if (c < FIN_GROUPS) { mc = s_part[c][AT_D]; lc = s_part[c][AT_D + 1]; }
+        else if (c < ncon) { mc = s_rec[(c - FIN_GROUPS) * AT_REC + AT_D]; lc = s_rec[(c - FIN_GROUPS) * AT_REC + AT_D + 1]; }
+        const float mw = wave_max_dpp(mc);
+        if (wave < 2 && lane == 0) s_red[wave] = mw;
+        __syncthreads();
+        const float M = fmaxf(s_red[0], s_red[1]);
+        const float w = (mc == -INFINITY) ? 0.f : __expf(mc - M);
+        if (c < ncon) s_w[c] = w;
+        const float lw = wave_tree_sum(w * lc);
+        if (wave < 2 && lane == 0) s_red[2 + wave] = lw;
+        __syncthreads();
+    }
+    {
+        const int d = tid & (AT_D - 1), part = tid >> 7;     // 8 parts x 128 dims
+        float a = 0.f;
+        for (int c = part; c < ncon; c += 8) {
+            const float x = c < FIN_GROUPS ? s_part[c][d] : s_rec[(c - FIN_GROUPS) * AT_REC + d];
+            a = __builtin_fmaf(x, s_w[c], a);
+        }
+        s_a[part][d] = a;
+    }
+    __syncthreads();
+    if (tid < AT_D) {
+        const float L = s_red[2] + s_red[3];
+        float a = ((s_a[0][tid] + s_a[1][tid]) + (s_a[2][tid] + s_a[3][tid])) +
+                  ((s_a[4][tid] + s_a[5][tid]) + (s_a[6][tid] + s_a[7][tid]));
+        out[(size_t)bq * AT_D + tid] = f2bf(a / L);
+    }
+}
+
+int skv_launch_attn_finish(const void* q, const void* k, const void* v, const void* ws, const int32_t* dst_slots,
+                           const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, long long kv_stride_h,
+                           int sparse_start, int rec_splits, float scale, hipStream_t st) {
+    if (Hkv < 1 || Hq % Hkv || S < 1 || S > 1024 || rec_splits < 1 || rec_splits > FIN_MAX_REC) return SKV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(skv_attn_finish_kernel, dim3(bs * Hq), dim3(FIN_GROUPS * 16), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const float*)ws, dst_slots, cnts, (bf16_t*)out, Hq / Hkv, S, kv_stride_h,
+                       sparse_start, rec_splits, scale);
+    return SKV_OK;
 }
 
 extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return (size_t)bs * Hq * splits * AT_REC * sizeof(float); }

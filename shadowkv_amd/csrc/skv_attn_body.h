@@ -1,0 +1,153 @@
+// Body of the split (flash-decoding) attention pass, shared by the standalone kernel (skv_attn.hip) and by the
+// attention role of the fused fetch kernel (skv_rebuild.hip).  See skv_attn.hip for the algorithm.
+//   MASKED: rows of the sparse region whose slot is listed in miss_slots[0 .. n_miss) are skipped (their K / V are
+//   being written by the other roles of the same launch); they are attended by skv_attn_finish_kernel afterwards.
+#pragma once
+#include "skv_common.h"
+
+#define AT_D 128
+#define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
+#define AT_REC 132     // floats per (head, split) record: acc[128], m, l, 2 pad (16-B aligned rows)
+
+template <int G, bool MASKED>
+__device__ __forceinline__ void skv_attn_partial_body(
+    const bf16_t* __restrict__ q,   // [bs][Hq][128]
+    const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
+    const bf16_t* __restrict__ v,
+    float* __restrict__ ws,         // [bs*Hkv][G][rec_splits][AT_REC]  (acc[128], m, l)
+    int kv_len, long long kv_stride_h /*elements*/, int splits /* ranges the rows are cut into */,
+    int rec_splits /* records per head in ws (>= splits) */, int split, int bh, float scale, float* s_dyn,
+    const int32_t* __restrict__ miss_slots, int n_miss, int sparse_start, int sparse_rows) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
+    const int per = (kv_len + splits - 1) / splits;
+    const int k0 = split * per, k1 = min(k0 + per, kv_len);
+    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_dyn + AT_GROUPS * G * (AT_D + 2));   // [32] when MASKED
+    if (MASKED) {
+        if (tid < 32) s_mask[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n_miss; i += 256) {
+            const int slot = miss_slots[i];
+            atomicOr(&s_mask[(slot >> 5) & 31], 1u << (slot & 31));
+        }
+        __syncthreads();
+    }
+
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        u32x4 w = *reinterpret_cast<const u32x4*>(q + ((size_t)bh * G + g) * AT_D + 8 * sub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[g][2 * j] = bf_lo(w[j]) * scale;
+            qf[g][2 * j + 1] = bf_hi(w[j]) * scale;
+        }
+    }
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+    const bf16_t* kb = k + (size_t)bh * kv_stride_h + 8 * sub;
+    const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
+    // A 16-lane group takes AT_KB keys per iteration (keys grp + 16*i): 2*AT_KB row loads in flight, the scores of
+    // the batch are reduced first, then ONE running-max update / accumulator rescale per batch instead of per key.
+    constexpr int AT_KB = 4;
+    for (int key0 = k0 + grp; key0 < k1; key0 += AT_GROUPS * AT_KB) {
+        u32x4 kr[AT_KB], vr[AT_KB];
+        bool alive[AT_KB];
+#pragma unroll
+        for (int i = 0; i < AT_KB; ++i) {
+            const int key = key0 + i * AT_GROUPS;
+            alive[i] = key < k1;
+            if (MASKED) {
+                const int rel = key - sparse_start;
+                if (rel >= 0 && rel < sparse_rows) alive[i] = alive[i] && !((s_mask[(rel >> 8) & 31] >> ((rel >> 3) & 31)) & 1u);
+            }
+            // dead keys read a row that is certainly valid and finite (their p is 0, but 0 * garbage could be NaN:
+            // a masked slot is being overwritten by the fetch roles of the same launch)
+            const int kc = alive[i] ? key : (MASKED ? 0 : k1 - 1);
+            kr[i] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * AT_D);
+            vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * AT_D);
+        }
+        float sc[AT_KB][G];
+#pragma unroll
+        for (int i = 0; i < AT_KB; ++i) {
+            float kf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bf_lo(kr[i][j]);
+                kf[2 * j + 1] = bf_hi(kr[i][j]);
+            }
+            const bool live = alive[i];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = __builtin_fmaf(qf[g][j], kf[j], s);
+                s = row16_tree_sum(s);
+                sc[i][g] = live ? s : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float mn = m[g];
+#pragma unroll
+            for (int i = 0; i < AT_KB; ++i) mn = fmaxf(mn, sc[i][g]);
+            // m = -inf on the first batch: exp(-inf) = 0.  MASKED: a whole batch can be dead before any live key was
+            // seen (mn = -inf): exp(-inf - -inf) would be NaN
+            const float corr = (MASKED && mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
+            float lsum = l[g] * corr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
+#pragma unroll
+            for (int i = 0; i < AT_KB; ++i) {
+                const float p = (MASKED && sc[i][g] == -INFINITY) ? 0.f : __expf(sc[i][g] - mn);   // dead keys: 0
+                lsum += p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[g][2 * j] = __builtin_fmaf(p, bf_lo(vr[i][j]), acc[g][2 * j]);
+                    acc[g][2 * j + 1] = __builtin_fmaf(p, bf_hi(vr[i][j]), acc[g][2 * j + 1]);
+                }
+            }
+            l[g] = lsum;
+            m[g] = mn;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[g][j];
+        if (sub == 0) {
+            s_part[grp][g][AT_D] = m[g];
+            s_part[grp][g][AT_D + 1] = l[g];
+        }
+    }
+    __syncthreads();
+    // merge the 16 groups: thread handles (g, d) pairs; G*128 outputs + G stats
+    for (int o = tid; o < G * AT_D; o += 256) {
+        const int g = o / AT_D, d = o % AT_D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
+        float a = 0.f, L = 0.f;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) {
+            float mr = s_part[r][g][AT_D];
+            float w = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+            a = __builtin_fmaf(s_part[r][g][d], w, a);
+            L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
+        }
+        float* dst = ws + (((size_t)bh * G + g) * rec_splits + split) * AT_REC;
+        dst[d] = a;
+        if (d == 0) {
+            dst[AT_D] = M;
+            dst[AT_D + 1] = L;
+        }
+    }
+}

@@ -20,6 +20,7 @@
 // Whole tiles below cnt*C exit early; rows below cnt*C inside a partial tile are computed but not
 // stored (they hold resident chunks).  The legacy entry point (pre-RoPE output buffer) shares the kernel.
 #include "skv_common.h"
+#include "skv_attn_body.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -35,7 +36,19 @@ __device__ __forceinline__ long long chunk_id_at(const void* ids, int ids64, siz
 
 // KS = rank / 32 k-steps (5 for rank 160); every loop below has a compile-time trip count so the
 // compiler batches the global loads of a phase instead of waiting on each one.
-template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/, int KS>
+// Optional third role of the launch (in-place layout only): split attention over every row that is NOT a miss slot.
+// Those rows (local, outliers, surviving chunks, generated tokens) are final before this launch starts, so their
+// attention runs on the CUs that the PCIe-bound V fetch leaves idle; the miss rows are attended afterwards by
+// skv_attn_finish_kernel, which also merges the records.
+struct AttnRole {
+    const bf16_t* q;          // [bs][Hq][128]
+    float* ws;                // [bs*Hq][rec_splits][AT_REC]
+    const int* kv_len_dev;    // nullable
+    int kv_len_host, splits, rec_splits;
+    float scale;
+};
+
+template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/, int KS, int AG = 0 /* attention role: G */>
 __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     const bf16_t* __restrict__ U,        // [bs][seq_len][R]
     const bf16_t* __restrict__ SV,       // [bs][heads][128][R]
@@ -55,7 +68,17 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     // stream fork/join around it.  Rebuild tiles come first in dispatch order (short, few), landing blocks fill
     // the remaining CUs and are PCIe-bound.
     int rebuild_tiles, const u32x4* __restrict__ v_host, u32x4* __restrict__ v_buf, const u32x4* __restrict__ v_temp,
-    long long v_host_stride_u128, long long v_stride_u128, long long v_off_u128) {
+    long long v_host_stride_u128, long long v_stride_u128, long long v_off_u128, int land_blocks, AttnRole ar) {
+    if constexpr (AG > 0) if ((int)blockIdx.x >= rebuild_tiles + land_blocks) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
+        const int bh3 = blockIdx.y, cnt3 = cnts ? cnts[bh3] : 0;
+        const int kv_len = ar.kv_len_dev ? *ar.kv_len_dev : ar.kv_len_host;
+        skv_attn_partial_body<AG, true>(
+            ar.q, out, reinterpret_cast<const bf16_t*>(v_buf), ar.ws, kv_len, out_stride_h, ar.splits, ar.rec_splits,
+            (int)blockIdx.x - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
+            dst_slots + (size_t)bh3 * S + cnt3, S - cnt3, out_row0, S * C);
+        return;
+    }
     if ((int)blockIdx.x >= rebuild_tiles) {
         const int bh2 = blockIdx.y, tid2 = threadIdx.x, unit = tid2 & 127, rsub = tid2 >> 7;
         const int cnt2 = cnts ? cnts[bh2] : 0;
@@ -247,13 +270,15 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     }
 }
 
+#include "skv_launch.h"
+
 // mode: 0 pre-RoPE (legacy batch_gather_gemm), 1 Llama, 2 GLM
 int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
                        const int32_t* cnts, void* out, int bs, int heads, int seq_len, int head_dim, int R, int S,
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
                        const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
-                       long long v_stride, long long v_off, hipStream_t st) {
+                       long long v_stride, long long v_off, hipStream_t st, const AttnLaunch* attn) {
     if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
     if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
     if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
@@ -268,12 +293,49 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
         if (!v_host || (!v_temp && !dst_slots) || !hit_offsets || (v_host_stride % 8) || (v_stride % 8) || (v_off % 8)) return SKV_ERR_ARG;
         land_blocks = (S + 7) / 8;
     }
-    dim3 grid(tiles + land_blocks, bs * heads), block(256);
+    AttnRole ar{};
+    int attn_g = 0;
+    size_t smem_all = smem;
+    if (attn) {
+        // attention role: in-place layout, rank 160, G in {4, 8}, V buffer laid out like the K buffer
+        if (!dst_slots || !v_buf || mode == 0 || R != 160 || (attn->G != 4 && attn->G != 8) || attn->splits < 1 ||
+            attn->rec_splits < attn->splits || v_stride != out_stride_h || out_stride_s != RB_D ||
+            out_stride_b != (long long)heads * out_stride_h || v_off != (long long)out_row0 * RB_D)
+            return SKV_ERR_UNSUPPORTED;
+        ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->splits,
+                      attn->rec_splits, attn->scale};
+        attn_g = attn->G;
+        const size_t need = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float) + 32 * sizeof(uint32_t);
+        if (need > smem_all) smem_all = need;
+    }
+    dim3 grid(tiles + land_blocks + (attn ? attn->splits : 0), bs * heads), block(256);
+    if (attn) {
+#define SKV_RBA(M, GG)                                                                                             \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set && smem_all > 64 * 1024) {                                                                   \
+            (void)hipFuncSetAttribute((const void*)skv_rebuild_kernel<M, 5, GG>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_all);                  \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((skv_rebuild_kernel<M, 5, GG>), grid, block, smem_all, st, (const bf16_t*)U,            \
+                           (const bf16_t*)SV, (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, \
+                           ids64, cs_stride, out_stride_b, out_stride_h, out_stride_s, out_row0,                   \
+                           (const bf16_t*)hit_temp, hit_offsets, dst_slots, tiles, (const u32x4*)v_host,           \
+                           (u32x4*)v_buf, (const u32x4*)v_temp, v_host_stride / 8, v_stride / 8, v_off / 8,        \
+                           land_blocks, ar);                                                                       \
+    } while (0)
+        if (mode == 1) { if (attn_g == 4) SKV_RBA(1, 4); else SKV_RBA(1, 8); }
+        else           { if (attn_g == 4) SKV_RBA(2, 4); else SKV_RBA(2, 8); }
+#undef SKV_RBA
+        return SKV_OK;
+    }
 #define SKV_RB(M, K)                                                                                               \
     hipLaunchKernelGGL((skv_rebuild_kernel<M, K>), grid, block, smem, st, (const bf16_t*)U, (const bf16_t*)SV,     \
                        (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, ids64, cs_stride,    \
                        out_stride_b, out_stride_h, out_stride_s, out_row0, (const bf16_t*)hit_temp, hit_offsets, dst_slots, tiles, \
-                       (const u32x4*)v_host, (u32x4*)v_buf, (const u32x4*)v_temp, v_host_stride / 8, v_stride / 8, v_off / 8)
+                       (const u32x4*)v_host, (u32x4*)v_buf, (const u32x4*)v_temp, v_host_stride / 8, v_stride / 8, v_off / 8, \
+                       land_blocks, ar)
 #define SKV_RB_K(M)                 \
     switch (R / 32) {               \
         case 5: SKV_RB(M, 5); break; \

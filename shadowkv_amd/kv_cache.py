@@ -423,6 +423,54 @@ class ShadowKVCache_CPU:
                                      kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
               "fetch_kv_inplace")
 
+    OVERLAP_SPLITS = 24   # split pass inside the fetch launch; the finish kernel merges them with the miss rows
+
+    def can_overlap_attention(self):
+        return (self.rank == 160 and self.chunk_size == 8 and self.head_dim == 128
+                and self.num_key_value_groups in (4, 8) and self.select_sets <= 1024)
+
+    def select_fetch_attend_inplace(self, layer_idx, query_states, cos_sin_cache, kv_len=0, kv_len_dev=None):
+        """select_fetch_inplace + sparse attention of one layer with the attention over the already-resident rows
+        (local, outliers, surviving chunks, generated tokens) running INSIDE the fetch launch, on the CUs the PCIe-bound
+        V fetch leaves idle; the miss rows are attended by a second, small launch that also merges everything.
+        4 launches + 1 (score, normalize, top-k/diff, rebuild||fetch||attention, finish).  Returns [bs, 1, Hq, D]
+        like tensor_op.sparse_attention_decode; same values up to the order of the f32 sums."""
+        if query_states.shape[-2] != 1:
+            raise ValueError("decode-time selection expects q_len == 1")
+        self.incoming_q_len = 1
+        lm = self.k_landmark[layer_idx]
+        if self._select_ws is None:
+            self.H2D()
+        if self._dst_slots is None:
+            self._dst_slots = torch.zeros_like(self.offsets)
+        q = query_states if query_states.is_contiguous() else query_states.contiguous()
+        L, st = lib(), current_stream_handle()
+        bs, Hq, D = q.shape[0], self.num_attention_heads, self.head_dim
+        SA = self.OVERLAP_SPLITS
+        ws = tensor_op.attention_workspace(q.device, bs, Hq, SA)
+        check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
+                                          ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
+                                          ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
+                                          self.num_key_value_groups, lm.shape[-2], self.select_sets,
+                                          1.0 / math.sqrt(128), st), "select_chunks_inplace")
+        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        vhost = self.v_cache_cpu[layer_idx]
+        U, SV = self.U[layer_idx], self.SV[layer_idx]
+        width = cos_sin_cache.shape[-1]
+        scale = 1.0 / math.sqrt(D)
+        check(L.skv_fetch_kv_attn_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
+                                          ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), ptr(q), ptr(ws),
+                                          ptr(kv_len_dev), int(kv_len), U.shape[0], self.num_key_value_heads, Hq,
+                                          U.shape[1], D, self.rank, self.select_sets, self.chunk_size,
+                                          cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
+                                          self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA, scale, st),
+              "fetch_kv_attn_inplace")
+        out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
+        check(L.skv_attn_finish_inplace(ptr(q), ptr(kbuf), ptr(vbuf), ptr(ws), ptr(self._dst_slots), ptr(self.cnts),
+                                        ptr(out), bs, Hq, self.num_key_value_heads, self.select_sets, kbuf.stride(1),
+                                        self.sparse_start, SA, scale, st), "attn_finish_inplace")
+        return out
+
     def note_kv_appended(self, incoming=1):
         """Bookkeeping half of update_kv_cache for callers that wrote the new K / V rows themselves
         (tensor_op.qkv_rope_update pushes them from the fused QKV kernel): advances the offsets once per token."""

@@ -78,11 +78,12 @@ def build_cos_sin_cache(cfg, max_pos, device, dtype):
 class DecoderLM:
     def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
-                 num_layers=None, chunk_layout="reference", v_offload=True):
+                 num_layers=None, chunk_layout="reference", v_offload=True, overlap_attention=False):
         if chunk_layout not in ("reference", "inplace"):
             raise ValueError("chunk_layout must be 'reference' (hits compacted to the front, the reference's slot order) "
                              "or 'inplace' (hits keep their slots, misses take the freed slots)")
         self.chunk_layout = chunk_layout     # used by forward_fused only; layer_compute follows the reference
+        self.overlap_attention = overlap_attention   # in-place layout: attention over resident rows inside the fetch launch
         if attn_mode not in ("shadowkv_cpu", "full"):
             raise ValueError("attn_mode must be 'shadowkv_cpu' (ShadowKV offload path) or 'full' (full-attention baseline)")
         self.attn_mode = attn_mode
@@ -212,12 +213,15 @@ class DecoderLM:
                 x, residual, layer.input_layernorm_weight, layer.input_layernorm_variance_epsilon, layer.wqkv,
                 layer.bqkv, self.cos_sin_cache, pos, row_idx, kbuf, vbuf, self.num_heads,
                 self.num_key_value_heads, q_override=None if q_table is None else q_table[l])
-            if not full and self.chunk_layout == "inplace":
-                c.select_fetch_inplace(l, q, self.cos_sin_cache)
-            elif not full:
-                ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
-                c.fetch_kv(l, ids, self.cos_sin_cache)
-            attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev)
+            if not full and self.chunk_layout == "inplace" and self.overlap_attention and c.can_overlap_attention():
+                attn = c.select_fetch_attend_inplace(l, q, self.cos_sin_cache, kv_len=kv_len, kv_len_dev=kv_len_dev)
+            else:
+                if not full and self.chunk_layout == "inplace":
+                    c.select_fetch_inplace(l, q, self.cos_sin_cache)
+                elif not full:
+                    ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+                    c.fetch_kv(l, ids, self.cos_sin_cache)
+                attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
             # residual add + RMSNorm ride in the gate/up GEMV's block-cooperative prologue (one launch when bs == 1
             # and hidden == 4096, bit-identical to add_rmsnorm + GEMV; otherwise norm_linear_decode splits it)

@@ -216,6 +216,17 @@ def rebuild_keys(U, SV, cos_sin, position_ids, cnts, cache, sparse_start, chunk_
 _attn_ws = {}
 
 
+def attention_workspace(device, bs, Hq, splits):
+    """Per (device, shape, stream) scratch for the split records of the attention kernels (streams may run
+    concurrently, so they never share one)."""
+    key = (device.index, bs, Hq, splits, current_stream_handle())
+    ws = _attn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
+    return ws
+
+
 def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, splits=None, out=None):
     """softmax(q K^T / sqrt(D)) V for q_len == 1 over the first kv_len rows of the cache views.
     q [bs, Hq, 1, D] or [bs, Hq, D]; k_cache / v_cache [bs, Hkv, rows, D] views of contiguous
@@ -233,11 +244,7 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
         q = q.contiguous()
     if splits is None:
         splits = max(1, min(32, 256 // max(1, bs * Hkv)))
-    key = (q.device.index, bs, Hq, splits, current_stream_handle())   # per stream: pipelines may run concurrently
-    ws = _attn_ws.get(key)
-    if ws is None:
-        ws = torch.empty(lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=q.device)
-        _attn_ws[key] = ws
+    ws = attention_workspace(q.device, bs, Hq, splits)
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
     check(lib().skv_sparse_attention(ptr(q), ptr(k_cache), ptr(v_cache), ptr(out), ptr(ws), ptr(kv_len_dev),

@@ -7,13 +7,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _make(seed=5, glm=False, layout="reference"):
+def _make(seed=5, glm=False, layout="reference", overlap=False):
     from shadowkv_amd import llama
     cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
                             num_attention_heads=8, num_key_value_heads=2, vocab_size=2000,
                             qkv_bias=glm, rope_style="glm" if glm else "neox")
     m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
-                        seed=seed, chunk_layout=layout)
+                        seed=seed, chunk_layout=layout, overlap_attention=overlap)
     llama.build_synthetic_context(m, 4608, seed=77)
     return m, llama
 
@@ -293,3 +293,43 @@ def test_inplace_layout_decodes_the_same_tokens_as_reference_layout():
         assert int(t1) == int(t2), i
         assert torch.equal(m1.kv_cache.position_ids.sort(dim=-1).values, m2.kv_cache.position_ids.sort(dim=-1).values), i
     assert not torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)   # the slot order does differ
+
+
+def test_overlapped_attention_graph_equals_eager_and_decodes_like_the_plain_path():
+    """chunk_layout='inplace' with overlap_attention: one step's logits agree with the plain in-place path (attention
+    differs only in the order of its f32 sums - on this tiny random model that can flip a greedy token, so logits are
+    compared, not tokens) with identical chunk bookkeeping; the captured step equals the eager step bit for bit."""
+    steps = 6
+    m0, llama = _make(layout="inplace")
+    m1, _ = _make(layout="inplace", overlap=True)
+    m2, _ = _make(layout="inplace", overlap=True)
+    assert m1.kv_cache.can_overlap_attention()
+    table = llama.make_walk_table(m0, steps, seed=3)
+    tok = torch.tensor([[17]], device=DEV)
+    logits = []
+    for m in (m0, m1):
+        c = m.kv_cache
+        row = c.sparse_end + c.gen_offset
+        pos = m.get_ctx(tok)
+        row_idx = torch.tensor([row], device=DEV, dtype=torch.long)
+        logits.append(m.forward_fused(tok, pos, row_idx, kv_len=row + 1, q_table=table[0]))
+        c.note_kv_appended(1)
+    torch.cuda.synchronize()
+    assert torch.equal(m0.kv_cache.position_ids, m1.kv_cache.position_ids)
+    assert torch.allclose(logits[0], logits[1], rtol=2e-2, atol=2e-2), float((logits[0] - logits[1]).abs().max())
+    # eager vs captured, both overlapped
+    m1, _ = _make(layout="inplace", overlap=True)
+    t1 = tok.clone()
+    toks1 = []
+    for i in range(steps):
+        t1 = m1.decode_step(t1, temperature=0.0, q_table=table[i])
+        toks1.append(int(t1))
+    dec = llama.GraphDecoder(m2, temperature=0.0, walk_table=table)
+    dec.token.copy_(tok)
+    warm = dec.capture(warmup=2)
+    toks2 = [int(dec.step()) for _ in range(steps - warm)]
+    torch.cuda.synchronize()
+    assert toks2 == toks1[warm:]
+    assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
+    assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
+    assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))

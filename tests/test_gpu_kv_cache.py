@@ -213,3 +213,39 @@ def test_v_table_in_hbm_gives_the_same_cache_bytes():
     assert torch.equal(a.position_ids, b.position_ids)
     assert_bits_equal(a.v_cache_buffer, b.v_cache_buffer)
     assert_bits_equal(a.k_cache_buffer, b.k_cache_buffer)
+
+
+@pytest.mark.parametrize("case", ["llama_cpu_b1024", "glm_small"])
+def test_overlapped_attention_equals_fetch_then_attend(case):
+    """select_fetch_attend_inplace (attention over the resident rows inside the fetch launch + finish kernel over the
+    miss rows) against select_fetch_inplace + sparse_attention_decode from the same state, several steps: identical
+    cache bytes / ids, attention outputs equal up to the order of the f32 sums, and both within the oracle's f64
+    attention tolerance."""
+    from shadowkv_amd import tensor_op
+    a, c, inp = _build(case)
+    b, _, _ = _build(case)
+    assert b.can_overlap_attention()
+    cs_dev = inp["cos_sin"].to(DEV)
+    kv, Hq, D = c["kv_heads"], c["q_heads"], c["head_dim"]
+    for t in range(inp["q_steps"].shape[0]):
+        qd = inp["q_steps"][t].to(DEV)
+        knew = torch.randn(1, kv, 1, D, generator=torch.Generator().manual_seed(t)).bfloat16().to(DEV)
+        vnew = torch.randn(1, kv, 1, D, generator=torch.Generator().manual_seed(50 + t)).bfloat16().to(DEV)
+        for cache in (a, b):
+            cache.update_kv_cache(knew, vnew, 0)
+        rows = a.sparse_end + a.gen_offset
+        a.select_fetch_inplace(0, qd, cs_dev)
+        o_ref = tensor_op.sparse_attention_decode(qd, a.k_cache_buffer[0], a.v_cache_buffer[0], kv_len=rows)
+        kvd = torch.tensor([rows], dtype=torch.int32, device=DEV)
+        o_new = b.select_fetch_attend_inplace(0, qd, cs_dev, kv_len=0, kv_len_dev=kvd) if t % 2 else \
+            b.select_fetch_attend_inplace(0, qd, cs_dev, kv_len=rows)
+        torch.cuda.synchronize()
+        assert torch.equal(a.position_ids, b.position_ids) and torch.equal(a.cnts, b.cnts)
+        assert_bits_equal(a.k_cache_buffer, b.k_cache_buffer)
+        assert_bits_equal(a.v_cache_buffer, b.v_cache_buffer)
+        assert o_new.shape == o_ref.shape
+        assert torch.allclose(o_new.float(), o_ref.float(), rtol=2 ** -7, atol=2e-3), float((o_new.float() - o_ref.float()).abs().max())
+        want = oracle.sparse_attention(qd.cpu().view(1, Hq, D), a.k_cache_buffer[0].cpu(), a.v_cache_buffer[0].cpu(),
+                                       rows, 1.0 / math.sqrt(D))
+        want = want[0] if isinstance(want, tuple) else want
+        assert torch.allclose(o_new.cpu().float().view(-1), want.float().view(-1), rtol=2 ** -6, atol=4e-3)
