@@ -10,6 +10,8 @@
 //           (m, l) per query head and accumulate p*V for their 8 output dims; the 16 groups of the
 //           workgroup are merged through LDS; (m, l, acc[128]) per (split, head) go to a workspace.
 //   pass 2  grid (bs*Hq): merges the splits, writes bf16.
+// In-place layout (skv_rebuild.hip runs pass 1 over the resident rows as a role of the fetch launch):
+//   skv_attn_finish_kernel  grid (bs*Hq) x 1024: attends the miss rows and merges them with the pass-1 records.
 // HBM-bound: 2 * kv_len * 256 B per (batch, kv head); K/V rows are read exactly once.
 // kv_len may come from device memory (kv_len_dev) so the launch sequence is graph-capturable.
 #include "../../include/shadowkv_hip.h"

@@ -35,7 +35,7 @@ def silu_and_mul(out, x):
     return out
 
 
-MAX_GEMV_ROWS = 16   # small batches: one native GEMV per token row (no hipBLASLt in the captured decode step)
+MAX_GEMV_ROWS = 16   # token rows served by the native kernels (1: GEMV, 2..16: small-M MFMA kernel); more -> F.linear
 
 
 def linear_decode(x, w, bias=None, fuse_silu_mul=False):
