@@ -66,6 +66,66 @@ def test_select_chunks(blocks, G, N, S):
     assert torch.equal(r0[3], r1[3]), "offsets differ"
 
 
+def _inplace_expected(cached, sel):
+    """Model of the in-place layout: ids selected again keep their slot; the misses (ascending id) take the slots of the
+    evicted ids (ascending slot).  Integer arithmetic only - the selected set `sel` comes from the oracle."""
+    blocks, S = cached.shape
+    exp = cached.clone(); cnts = []; miss_ids = []; dst = []
+    for b in range(blocks):
+        chosen = set(sel[b].tolist())
+        resident = cached[b].tolist()
+        keep = [i for i, cid in enumerate(resident) if cid in chosen and cid >= 0 and resident.index(cid) == i]
+        kept_ids = {resident[i] for i in keep}
+        free = [i for i in range(S) if i not in set(keep)]
+        misses = sorted(chosen - kept_ids)
+        assert len(free) == len(misses)
+        for slot, cid in zip(free, misses):
+            exp[b, slot] = cid
+        cnts.append(len(keep)); miss_ids.append(misses); dst.append(free)
+    return exp, cnts, miss_ids, dst
+
+
+@pytest.mark.parametrize("blocks,G,N,S,overlap", [(8, 4, 15560, 256, 0.67), (4, 4, 4000, 256, 0.0), (4, 4, 4000, 256, 1.0),
+                                                   (2, 8, 2000, 32, 0.5), (2, 4, 5000, 1024, 0.3), (3, 2, 300, 300, 1.0)])
+def test_select_chunks_inplace(blocks, G, N, S, overlap):
+    """skv_select_chunks_inplace: the selected SET is the oracle's (bit-exact top-k), the slot assignment follows the
+    in-place rule exactly; all-hit (nothing written), all-miss (incl. the -1 initial state) and S = 1024 covered."""
+    L = _lib()
+    g = torch.Generator().manual_seed(7 * N + S)
+    q = (torch.randn(blocks, G, 128, generator=g) * 3).bfloat16()
+    lm = torch.randn(blocks, N, 128, generator=g).bfloat16()
+    lm_idx = torch.stack([torch.sort(torch.randperm(N + 48, generator=g)[:N]).values for _ in range(blocks)]).to(torch.int64)
+    _, sel, _, _, _ = _oracle_select(q, lm, lm_idx, lm_idx[:, :S].contiguous(), blocks, G, N, S)
+    cached = torch.empty(blocks, S, dtype=torch.int64)
+    for b in range(blocks):
+        chosen = sel[b][torch.randperm(S, generator=g)]
+        n_keep = int(round(overlap * S))
+        others = torch.tensor(sorted(set(lm_idx[b].tolist()) - set(sel[b].tolist())))
+        filler = others[torch.randperm(len(others), generator=g)[:S - n_keep]] if n_keep < S else others[:0]
+        if overlap == 0.0 and b == 0:
+            filler = torch.full((S,), -1, dtype=torch.int64)              # the cache's initial state
+        row = torch.cat([chosen[:n_keep], filler])
+        cached[b] = row[torch.randperm(S, generator=g)]
+    exp, cnts, miss_ids, dst = _inplace_expected(cached, sel)
+    ws = torch.empty(L.lib().skv_select_workspace_bytes(blocks, G, N), dtype=torch.uint8, device=DEV)
+    c = cached.to(DEV)
+    mids = torch.full((blocks, S), -7, dtype=torch.int32, device=DEV); slots = torch.full((blocks, S), -7, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(blocks, dtype=torch.int32, device=DEV); sel_out = torch.zeros(blocks, S, dtype=torch.int64, device=DEV)
+    qd, lmd, lid = q.to(DEV), lm.to(DEV), lm_idx.to(DEV)
+    L.check(L.lib().skv_select_chunks_inplace(qd.data_ptr(), lmd.data_ptr(), lid.data_ptr(), c.data_ptr(), mids.data_ptr(),
+                                              slots.data_ptr(), cnt.data_ptr(), ws.data_ptr(), 0, sel_out.data_ptr(),
+                                              blocks, G, N, S, ALPHA, _stream()), "select_chunks_inplace")
+    torch.cuda.synchronize()
+    assert torch.equal(sel_out.cpu(), sel)
+    assert cnt.cpu().tolist() == cnts
+    assert torch.equal(c.cpu(), exp)
+    for b in range(blocks):
+        k = cnts[b]
+        assert mids[b, k:].cpu().tolist() == miss_ids[b]
+        assert slots[b, k:].cpu().tolist() == dst[b]
+        assert torch.all(mids[b, :k] == -7) and torch.all(slots[b, :k] == -7)     # nothing written for hits
+
+
 def test_select_chunks_ties():
     """Massive ties at the threshold: duplicated landmarks give identical bf16 scores; the contract
     (lowest landmark slot wins) must hold bit-exactly."""
