@@ -311,6 +311,16 @@ SKV_EXPORT int skv_attn_finish_inplace(const void* q, const void* k_cache, const
                             int kv_heads, int select_sets, long long kv_head_stride, int sparse_start, int attn_splits,
                             float scale, skv_stream_t stream);
 
+/* End of a decode step in one launch: top-p filter over the k <= 64 sorted top-k logits (vals = logits / temperature,
+ * descending; idx their token ids), multinomial draw (sample_token, /root/reference/models/tensor_op.py:242-297) written
+ * to token[bs], and the device-side step counters advanced: pos[b] += 1; gen = (gen + 1) % slack; row_idx = gen + base;
+ * kv_len = row_idx + 1; step_idx = (step_idx + 1) % table_len (step_idx nullable).  Randomness: counter-based hash of
+ * (seed, pos[b], b, lane) - reproducible and graph-capturable. */
+SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,
+                       unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
+                       int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
+                       skv_stream_t stream);
+
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 
 /* Chunk means (landmark candidates) and per-chunk minimum cosine similarity (outlier score) of the post-RoPE keys,

@@ -71,7 +71,11 @@ __global__ __launch_bounds__(FIN_GROUPS * 16) void skv_attn_finish_kernel(
     __shared__ int s_slot[1024];
     __shared__ float s_part[FIN_GROUPS][AT_D + 2];
     __shared__ __attribute__((aligned(16))) float s_rec[FIN_MAX_REC * AT_REC];
-    const int bq = blockIdx.x, bh = bq / G;
+    // XCD-aware block -> head mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the G
+    // query heads of one KV head read the same K / V rows, so they get block indices that are equal modulo the number of
+    // KV heads (8 at the headline shape -> same XCD, the rows come out of one L2).
+    const int nkv = gridDim.x / G;
+    const int bq = ((int)blockIdx.x % nkv) * G + (int)blockIdx.x / nkv, bh = bq / G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
     // the whole destination list of this head is requested before the hit count is known (no dependent round trip)

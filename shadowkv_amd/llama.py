@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import tensor_op
+from ._lib import lib, check, ptr, current_stream_handle
 from .kv_cache import KV_Cache, ShadowKVCache_CPU
 
 
@@ -363,8 +364,9 @@ class GraphDecoder:
     At bs = 1 a decode step is ~25 launches per layer; eager PyTorch is host-bound on that
     (MI355X_MICROARCH.md "graph-replay-floor"), the graph removes the per-launch host cost."""
 
-    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None):
+    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None, seed=1234):
         self.m = model
+        self.seed = int(seed)
         self.temperature, self.top_p, self.top_k = temperature, top_p, top_k
         c = model.kv_cache
         dev = model.device
@@ -424,7 +426,18 @@ class GraphDecoder:
         if self.walk_table is not None:
             qstep = torch.index_select(self.walk_table, 0, self.step_idx)[0]
         logits = m.forward_fused(self.token, self.pos, self.row_idx, kv_len=0, kv_len_dev=self.kv_len, q_table=qstep)
-        self.token.copy_(self._sample(logits[:, -1, :]))
+        last = logits[:, -1, :]
+        k = min(self.top_k, last.size(-1)) if self.top_k > 0 else last.size(-1)
+        if self.temperature > 0.0 and k <= 64 and last.is_cuda:
+            # top-k by torch, then ONE native launch: top-p filter, draw, and every device-side counter of the step
+            vals, idx = self._topk(last / self.temperature, k)
+            tlen = self.walk_table.shape[0] if self.walk_table is not None else 1
+            check(lib().skv_sample_advance(ptr(vals), ptr(idx), vals.shape[0], k, float(self.top_p), self.seed,
+                                           ptr(self.token), ptr(self.pos), ptr(self.gen), ptr(self.row_idx),
+                                           ptr(self.kv_len), ptr(self.step_idx) if self.walk_table is not None else 0,
+                                           self.base, self.slack, tlen, current_stream_handle()), "sample_advance")
+            return
+        self.token.copy_(self._sample(last))
         # advance the device-side counters (generated-row slack wraps like the host bookkeeping in step())
         self.pos.add_(1)
         self.gen.copy_((self.gen + 1) % self.slack)

@@ -333,3 +333,48 @@ def test_overlapped_attention_graph_equals_eager_and_decodes_like_the_plain_path
     assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
     assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
     assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
+
+
+def test_sample_advance_kernel_distribution_and_counters():
+    """skv_sample_advance: top-p semantics of tensor_op.sample_token (first token always kept; token i kept iff the
+    cumulative probability BEFORE it is <= top_p), multinomial frequencies, and the step counters (wrap included)."""
+    from shadowkv_amd import _lib
+    L = _lib.lib()
+    bs, k = 3, 50
+    idx = torch.arange(1000, 1000 + bs * k, device=DEV, dtype=torch.long).view(bs, k)
+    token = torch.zeros(bs, 1, dtype=torch.long, device=DEV)
+    pos = torch.tensor([[10], [20], [30]], dtype=torch.long, device=DEV)
+    gen = torch.tensor([93], dtype=torch.long, device=DEV); row = torch.zeros(1, dtype=torch.long, device=DEV)
+    kvl = torch.zeros(1, dtype=torch.int32, device=DEV); step = torch.tensor([5], dtype=torch.long, device=DEV)
+
+    def run(vals, top_p, n):
+        out = []
+        for _ in range(n):
+            _lib.check(L.skv_sample_advance(_lib.ptr(vals), _lib.ptr(idx), bs, k, top_p, 77, _lib.ptr(token), _lib.ptr(pos),
+                                            _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), _lib.ptr(step), 2496, 96, 7,
+                                            _lib.current_stream_handle()), "sample_advance")
+            out.append(token.flatten().clone())
+        torch.cuda.synchronize()
+        return torch.stack(out)
+
+    # row 0: one dominant logit (p0 > top_p -> only token 0 survives); row 1: four equal logits far above the rest with
+    # top_p = 0.9 (cumulative 0, .25, .5, .75 <= .9 -> four kept, the fifth sees 1.0 > .9); row 2: same as row 1
+    vals = torch.full((bs, k), -30.0, device=DEV)
+    vals[0, 0] = 5.0
+    vals[1:, :4] = 2.0
+    vals, _ = vals.sort(dim=-1, descending=True)
+    draws = run(vals.contiguous(), 0.9, 2000)
+    assert torch.all(draws[:, 0] == 1000)
+    for b in (1, 2):
+        rel = draws[:, b] - (1000 + b * k)
+        assert rel.min() >= 0 and rel.max() <= 3
+        freq = torch.bincount(rel, minlength=4).float() / draws.shape[0]
+        assert torch.all((freq - 0.25).abs() < 0.04), freq
+    assert not torch.equal(draws[:, 1] - 1050, draws[:, 2] - 1100)          # rows draw independently
+    # counters after 2000 steps from (pos 10/20/30, gen 93, step 5)
+    assert pos.flatten().tolist() == [2010, 2020, 2030]
+    assert int(gen) == (93 + 2000) % 96 and int(row) == int(gen) + 2496 and int(kvl) == int(row) + 1
+    assert int(step) == (5 + 2000) % 7
+    # top_p = 0 disables the nucleus filter: the tail (p ~ 1e-14) is still never drawn, the four tokens are
+    draws = run(vals.contiguous(), 0.0, 200)
+    assert (draws[:, 1] - 1050).max() <= 3
