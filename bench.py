@@ -259,7 +259,8 @@ def main():
     model = llama.DecoderLM(cfg=cfg, batch_size=bs, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
                             chunk_size=8, num_layers=args.layers, seed=1234 + rank,
                             attn_mode="full" if full else "shadowkv_cpu", chunk_layout=args.layout,
-                            v_offload=args.v_table == "host", overlap_attention=bool(args.overlap_attention))
+                            v_offload=args.v_table == "host", overlap_attention=bool(args.overlap_attention),
+                            max_new_tokens=max(1024, args.warmup + args.steps + 64))
     if bs > 1:
         args.no_cpu_baseline = True
     if full:

@@ -79,7 +79,7 @@ def build_cos_sin_cache(cfg, max_pos, device, dtype):
 class DecoderLM:
     def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
-                 num_layers=None, chunk_layout="reference", v_offload=True, overlap_attention=False):
+                 num_layers=None, chunk_layout="reference", v_offload=True, overlap_attention=False, max_new_tokens=1024):
         if chunk_layout not in ("reference", "inplace"):
             raise ValueError("chunk_layout must be 'reference' (hits compacted to the front, the reference's slot order) "
                              "or 'inplace' (hits keep their slots, misses take the freed slots)")
@@ -108,7 +108,10 @@ class DecoderLM:
         self.norm_weight = torch.ones(cfg.hidden_size, device=self.device, dtype=dtype)
         self.norm_variance_epsilon = cfg.rms_norm_eps
         self.layers = [DecoderLayer(cfg, self.device, dtype, gen) for _ in range(self.num_layers)]
-        self.cos_sin_cache = build_cos_sin_cache(cfg, max_length + 1024, self.device, dtype)
+        # RoPE rows for the context plus every position decode can reach (the kernels index it with the device-side
+        # position counter: it must never run past the table)
+        self.max_new_tokens = int(max_new_tokens)
+        self.cos_sin_cache = build_cos_sin_cache(cfg, max_length + self.max_new_tokens, self.device, dtype)
 
         class _CacheCfg:
             num_hidden_layers = self.num_layers
