@@ -21,8 +21,13 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifndef RG_WAVES
 #define RG_WAVES 8
-#define RG_U 8  // MFMA steps (16-B loads per operand) in flight per wave
+#endif
+#ifndef RG_U
+#define RG_U 8
+#endif
+// RG_WAVES: waves per 16-row tile (K split);  RG_U: MFMA steps (16-B loads per operand) in flight per wave
 
 template <bool SILU_PAIR>
 __global__ __launch_bounds__(RG_WAVES * 64) void skv_rows_gemm_kernel(const bf16_t* __restrict__ W,
