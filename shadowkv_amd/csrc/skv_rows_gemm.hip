@@ -29,7 +29,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #endif
 // RG_WAVES: waves per 16-row tile (K split);  RG_U: MFMA steps (16-B loads per operand) in flight per wave
 
-template <bool SILU_PAIR>
+// PAIRX (M <= 8): token columns 8..15 of the MFMA are never stored, so their lanes (a >= 8) load the token operand of
+// the NEXT k-step instead (token a - 8) and hand it over with one DPP row rotate: one token-operand load serves two
+// MFMA steps (an ablation showed these L2 loads costing ~20 % of the kernel, profiles/r01_mfma_counters.txt).
+template <bool SILU_PAIR, bool PAIRX>
 __global__ __launch_bounds__(RG_WAVES * 64) void skv_rows_gemm_kernel(const bf16_t* __restrict__ W,
                                                                       const bf16_t* __restrict__ X,
                                                                       const bf16_t* __restrict__ bias,
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(RG_WAVES * 64) void skv_rows_gemm_kernel(const bf16
         if (row >= N) row = N - 1;
     }
     const bf16_t* wp = W + (size_t)row * K + 8 * g;
-    const bf16_t* xp = X + (size_t)(a < M ? a : M - 1) * K + 8 * g;
+    const int tokl = PAIRX ? (a & 7) : a;
+    const bf16_t* xp = X + (size_t)(tokl < M ? tokl : M - 1) * K + 8 * g + (PAIRX ? (a >> 3) * 32 : 0);
     const int S = K / 32, per = (S + RG_WAVES - 1) / RG_WAVES;
     const int s0 = wave * per, s1 = min(S, s0 + per);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -56,9 +60,19 @@ __global__ __launch_bounds__(RG_WAVES * 64) void skv_rows_gemm_kernel(const bf16
     for (; s + RG_U <= s1; s += RG_U) {
         u32x4 wv[RG_U], xv[RG_U];
 #pragma unroll
-        for (int u = 0; u < RG_U; ++u) {
+        for (int u = 0; u < RG_U; ++u)
             wv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(s + u) * 32));
-            xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(s + u) * 32);
+        if (PAIRX) {
+#pragma unroll
+            for (int u = 0; u < RG_U; u += 2) {   // lanes a < 8: step s+u, lanes a >= 8: step s+u+1 (pointer offset above)
+                xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(s + u) * 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[u + 1][j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xv[u][j], 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < RG_U; ++u) xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(s + u) * 32);
         }
 #pragma unroll
         for (int u = 0; u < RG_U; u += 2) {
@@ -68,9 +82,10 @@ __global__ __launch_bounds__(RG_WAVES * 64) void skv_rows_gemm_kernel(const bf16
                                                            __builtin_bit_cast(bf16x8, xv[u + 1]), acc1, 0, 0, 0);
         }
     }
+    const bf16_t* xs = X + (size_t)(tokl < M ? tokl : M - 1) * K + 8 * g;   // single steps: every lane its own step
     for (; s < s1; ++s) {
         u32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)s * 32));
-        u32x4 xv = *reinterpret_cast<const u32x4*>(xp + (size_t)s * 32);
+        u32x4 xv = *reinterpret_cast<const u32x4*>(xs + (size_t)s * 32);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xv),
                                                        acc0, 0, 0, 0);
     }
@@ -110,11 +125,19 @@ extern "C" int skv_linear_rows_bf16(const void* W, const void* X, const void* bi
     if (fuse_silu_mul) {
         if (N % 2 || bias) return SKV_ERR_ARG;
         const int I = N / 2;
-        hipLaunchKernelGGL((skv_rows_gemm_kernel<true>), dim3((I + 7) / 8), dim3(RG_WAVES * 64), 0, st, (const bf16_t*)W,
-                           (const bf16_t*)X, (const bf16_t*)nullptr, (bf16_t*)Y, N, K, M, I);
+        if (M <= 8)
+            hipLaunchKernelGGL((skv_rows_gemm_kernel<true, true>), dim3((I + 7) / 8), dim3(RG_WAVES * 64), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)X, (const bf16_t*)nullptr, (bf16_t*)Y, N, K, M, I);
+        else
+            hipLaunchKernelGGL((skv_rows_gemm_kernel<true, false>), dim3((I + 7) / 8), dim3(RG_WAVES * 64), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)X, (const bf16_t*)nullptr, (bf16_t*)Y, N, K, M, I);
     } else {
-        hipLaunchKernelGGL((skv_rows_gemm_kernel<false>), dim3((N + 15) / 16), dim3(RG_WAVES * 64), 0, st,
-                           (const bf16_t*)W, (const bf16_t*)X, (const bf16_t*)bias, (bf16_t*)Y, N, K, M, 0);
+        if (M <= 8)
+            hipLaunchKernelGGL((skv_rows_gemm_kernel<false, true>), dim3((N + 15) / 16), dim3(RG_WAVES * 64), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)X, (const bf16_t*)bias, (bf16_t*)Y, N, K, M, 0);
+        else
+            hipLaunchKernelGGL((skv_rows_gemm_kernel<false, false>), dim3((N + 15) / 16), dim3(RG_WAVES * 64), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)X, (const bf16_t*)bias, (bf16_t*)Y, N, K, M, 0);
     }
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
