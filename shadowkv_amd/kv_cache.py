@@ -24,6 +24,13 @@ MI355X-first differences that do not change results:
   * the host V stride passed to the mover is the tensor's real stride (max_length // C chunks); the
     reference passes the prompt length (kv_cache.py:1090), identical whenever prompt == max_length.
   * top-k membership under exact bf16 ties is defined (lowest landmark slot); torch.topk's is not.
+
+Beyond the reference's surface (opt-in, used by DecoderLM.forward_fused / bench.py):
+  * select_fetch_inplace / select_fetch_attend_inplace: the same decode step with an in-place resident set (chunks
+    selected again keep their slot, misses take the freed slots) and, optionally, the attention over the resident rows
+    inside the PCIe-bound fetch launch - same chunk set, K / V bytes and attention values (up to summation order).
+  * v_offload=False keeps the chunked V table in HBM; svd_mode="gram" factorises through K^T K;
+    prefill_kv_cache computes chunk means / outlier scores in one native pass when the keys are on the GPU.
 """
 import gc
 import math
