@@ -49,8 +49,8 @@ def _device_select(q, lm, lm_idx, cached, blocks, G, N, S):
 
 
 @pytest.mark.parametrize("blocks,G,N,S", [(8, 4, 15560, 256), (8, 4, 504, 32), (4, 8, 25544, 256), (2, 1, 1000, 128),
-                                           (3, 4, 300, 300)])
-def test_select_chunks(blocks, G, N, S):
+                                           (3, 4, 300, 300), (2, 4, 131056, 256)])   # last: 1M-token context, score row
+def test_select_chunks(blocks, G, N, S):                                              # too large for LDS staging
     g = torch.Generator().manual_seed(N + S)
     q = (torch.randn(blocks, G, 128, generator=g) * 3).bfloat16()
     lm = torch.randn(blocks, N, 128, generator=g).bfloat16()
