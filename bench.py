@@ -33,6 +33,9 @@ WORKLOADS = {
     "llama3_1048k_131072": ("LLAMA_3_8B_1048K", 131072, 2048),
     "glm4_200k": ("GLM_4_9B_1M", 200 * 1024, 2048),
     "llama31_4k": ("LLAMA_3_1_8B", 4104, 256),
+    # not a BASELINE.json configuration: the 1M-token model at its full context on one GPU (10.7 GB of U, 8.6 GB of
+    # landmarks in HBM, 69 GB of V chunks in pinned host memory)
+    "llama3_1048k_full": ("LLAMA_3_8B_1048K", 1048576, 2048),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
