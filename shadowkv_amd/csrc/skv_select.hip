@@ -193,15 +193,19 @@ template <int G>
 __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
     const bf16_t* __restrict__ D, const float* __restrict__ part_max, const float* __restrict__ part_sum,
     bf16_t* __restrict__ P /* nullable, [B][G][N] */, bf16_t* __restrict__ score /* [B][score_stride] */, int N, int T,
-    int score_stride) {
-    const int b = blockIdx.y, t = blockIdx.x;
+    int score_stride, int tiles_per_block) {
+    const int b = blockIdx.y, t0 = blockIdx.x * tiles_per_block;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_m[G], s_inv[G];
-    // the column's G logits do not depend on the statistics: request them first (one memory round trip, not two)
-    const int col = t * SKV_TILE + tid;
+    // the first tile's G logits do not depend on the statistics: request them first (one memory round trip, not two)
     bf16_t dreg[G];
+    {
+        const int col = t0 * SKV_TILE + tid;
 #pragma unroll
-    for (int g = 0; g < G; ++g) dreg[g] = col < N ? D[((size_t)b * G + g) * N + col] : (bf16_t)0;
+        for (int g = 0; g < G; ++g) dreg[g] = col < N ? D[((size_t)b * G + g) * N + col] : (bf16_t)0;
+    }
+    // every workgroup recomputes the finals from the T partials (no cross-workgroup hand-off); long contexts give a
+    // workgroup several tiles so that this stays a small fraction of its work (tiles_per_block, chosen by the launcher)
     for (int g = wave; g < G; g += 4) {
         float mx, inv;
         softmax_finalize_wave(part_max + (size_t)b * T * G + g, part_sum + (size_t)b * T * G + g, T, G, lane, mx, inv);
@@ -211,16 +215,23 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
         }
     }
     __syncthreads();
-    if (col >= N) return;
-    bf16_t best = 0;
+    for (int tt = 0; tt < tiles_per_block; ++tt) {
+        const int col = (t0 + tt) * SKV_TILE + tid;
+        if (col >= N) return;
+        if (tt > 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const size_t o = ((size_t)b * G + g) * N + col;
-        bf16_t p = f2bf(spec_exp(bf2f(dreg[g]) - s_m[g]) * s_inv[g]);
-        if (P) P[o] = p;
-        best = p > best ? p : best;  // p >= 0: unsigned order == float order
+            for (int g = 0; g < G; ++g) dreg[g] = D[((size_t)b * G + g) * N + col];
+        }
+        bf16_t best = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const size_t o = ((size_t)b * G + g) * N + col;
+            bf16_t p = f2bf(spec_exp(bf2f(dreg[g]) - s_m[g]) * s_inv[g]);
+            if (P) P[o] = p;
+            best = p > best ? p : best;  // p >= 0: unsigned order == float order
+        }
+        score[(size_t)b * score_stride + col] = best;
     }
-    score[(size_t)b * score_stride + col] = best;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -311,7 +322,10 @@ __device__ __forceinline__ void select_bin_desc_wave0(const int* hist, int k, in
     }
 }
 
-template <bool STAGE_LDS>
+// SRC: where the selection passes read the score row: 1 = staged in LDS (<= ~60 K scores), 0 = global memory / L2 every
+// pass (longer rows: at 131 K scores = 1M-token context the kernel is VALU-bound on its one CU per head, 52 us; holding
+// the thread's segment in registers instead was measured 57 us)
+template <int SRC>
 __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     const bf16_t* __restrict__ score,      // [B][score_stride] (nullable: then cur_in is used)
     const int64_t* __restrict__ lm_idx,    // [B][N] slot -> chunk id (nullable: identity)
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     int* s_wave = s_hist + 256;   // [32]
     int* s_out = s_wave + 32;     // [8]
     int* s_histp = s_out + 8;     // [256][32] lane-privatised pass-1 histogram (copy = lane & 31 -> bank = copy)
-    bf16_t* s_score = reinterpret_cast<bf16_t*>(s_histp + 256 * 32);  // [score_stride] when STAGE_LDS
+    bf16_t* s_score = reinterpret_cast<bf16_t*>(s_histp + 256 * 32);  // [score_stride] when SRC == 1
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the resident id of this thread's slot is requested now: its (cold) latency overlaps the selection passes
     const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         s_byslot[i] = -1;
         s_rank[i] = 0;
     }
-    auto insert_resident = [&]() {
+    auto insert_resident = [&]() __attribute__((always_inline)) {
         if (tid < S && my_cached >= 0) {
             unsigned pos = (unsigned)my_cached & (unsigned)(H - 1);
             for (int probe = 0; probe < H; ++probe) {
@@ -367,8 +381,11 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     if (score != nullptr) {
         const bf16_t* gsc = score + (size_t)b * score_stride;
         const u32x4* gvec = reinterpret_cast<const u32x4*>(gsc);
-        const u32x4* svec = STAGE_LDS ? reinterpret_cast<const u32x4*>(s_score) : gvec;
+        const u32x4* svec = SRC == 1 ? reinterpret_cast<const u32x4*>(s_score) : gvec;
         const int nvec = score_stride / 8;
+        // thread-owned contiguous segment of `segv` 8-score vectors (ordered compaction)
+        const int segv = (nvec + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
+        const int v0 = min(tid * segv, nvec), v1 = min(v0 + segv, nvec);
         TOPK_STAMP(0);
         for (int i = tid; i < 256 * 32; i += SKV_SEL_THREADS) s_histp[i] = 0;
         __syncthreads();
@@ -379,9 +396,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         // bank c, so a wave instruction is conflict-free whatever the value distribution (lanes l and l+32 pair up).
         // A vector whose 8 scores share their high byte adds 8 with one atomic.
         const int cpy = lane & 31;
-        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
-            const u32x4 v = gvec[i];
-            if (STAGE_LDS) reinterpret_cast<u32x4*>(s_score)[i] = v;
+        auto hist1 = [=](int i, const u32x4 v) __attribute__((always_inline)) {
             const int b0 = (int)((v[0] >> 8) & 0xff);
             bool uniform = i * 8 + 7 < N;
 #pragma unroll
@@ -396,6 +411,11 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
                     if (i * 8 + e < N) atomicAdd(&s_histp[(val >> 8) * 32 + cpy], 1);
                 }
             }
+        };
+        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
+            const u32x4 v = gvec[i];
+            if (SRC == 1) reinterpret_cast<u32x4*>(s_score)[i] = v;
+            hist1(i, v);
         }
         insert_resident();   // (hash arrays were initialised before the barrier above)
         __syncthreads();
@@ -414,14 +434,14 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         __syncthreads();
         TOPK_STAMP(2);
         // ---- pass 2: histogram of the low byte inside that bin (values spread over many bins: plain atomics)
-        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) {
-            const u32x4 v = svec[i];
+        auto hist2 = [=](int i, const u32x4 v) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
                 if ((i * 8 + e < N) && ((val >> 8) == hi)) atomicAdd(&s_hist[val & 0xff], 1);
             }
-        }
+        };
+        for (int i = tid; i < nvec; i += SKV_SEL_THREADS) hist2(i, svec[i]);
         __syncthreads();
         TOPK_STAMP(3);
         if (wave == 0) select_bin_desc_wave0(s_hist, S - above_hi, s_out + 2, lane);
@@ -429,20 +449,22 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         const int thr = (hi << 8) | s_out[2];
         const int need_eq = S - (above_hi + s_out[3]);
         TOPK_STAMP(4);
-        // ---- pass 3: ordered compaction; thread owns `segv` consecutive 8-element vectors
-        const int segv = (nvec + SKV_SEL_THREADS - 1) / SKV_SEL_THREADS;
-        const int v0 = min(tid * segv, nvec), v1 = min(v0 + segv, nvec);
-        int c_gt = 0, c_eq = 0;
-        for (int i = v0; i < v1; ++i) {
-            const u32x4 v = svec[i];
+        // ---- pass 3: ordered compaction over the thread's segment
+        // (the lambdas below take and return their counters by value: captured references would pin them to scratch)
+        struct Cnt { int gt, eq; };
+        auto count = [=](int i, const u32x4 v, Cnt c) __attribute__((always_inline)) -> Cnt {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
                 const bool in = i * 8 + e < N;
-                c_gt += in && val > thr;
-                c_eq += in && val == thr;
+                c.gt += in && val > thr;
+                c.eq += in && val == thr;
             }
-        }
+            return c;
+        };
+        Cnt cc{0, 0};
+        for (int i = v0; i < v1; ++i) cc = count(i, svec[i], cc);
+        const int c_gt = cc.gt, c_eq = cc.eq;
         TOPK_STAMP(5);
         int gt_before = c_gt, eq_before = c_eq;
         block_scan_incl2(gt_before, eq_before, s_wave, tid);
@@ -450,28 +472,26 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
         gt_before -= c_gt;
         eq_before -= c_eq;
         // one candidate: exact rank among the selected (ties at the threshold -> lowest slot first)
-#define SKV_ASSIGN(VAL, J)                                                 \
-    do {                                                                   \
-        int pos = -1;                                                      \
-        if ((VAL) > thr) {                                                 \
-            pos = gt_before + min(eq_before, need_eq);                     \
-            ++gt_before;                                                   \
-        } else if ((VAL) == thr) {                                         \
-            if (eq_before < need_eq) pos = gt_before + eq_before;          \
-            ++eq_before;                                                   \
-        }                                                                  \
-        if (pos >= 0) s_cur[pos] = (J);                                    \
-    } while (0)
-        for (int i = v0; i < v1; ++i) {
-            const u32x4 v = svec[i];
+        auto assign = [=](int i, const u32x4 v, Cnt c) __attribute__((always_inline)) -> Cnt {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int val = (e & 1) ? (int)(v[e >> 1] >> 16) : (int)(v[e >> 1] & 0xffffu);
                 const int j = i * 8 + e;
-                if (j < N) SKV_ASSIGN(val, j);
+                if (j >= N) continue;
+                int pos = -1;
+                if (val > thr) {
+                    pos = c.gt + min(c.eq, need_eq);
+                    ++c.gt;
+                } else if (val == thr) {
+                    if (c.eq < need_eq) pos = c.gt + c.eq;
+                    ++c.eq;
+                }
+                if (pos >= 0) s_cur[pos] = j;
             }
-        }
-#undef SKV_ASSIGN
+            return c;
+        };
+        Cnt before{gt_before, eq_before};
+        for (int i = v0; i < v1; ++i) before = assign(i, svec[i], before);
         __syncthreads();
         // slot -> chunk id for the S selected slots: one parallel gather (not inside the serial loop above)
         if (tid < S) {
@@ -611,9 +631,11 @@ int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void
 int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
                                   int score_stride, int B, int G, int N, hipStream_t st) {
     const int T = (N + SKV_TILE - 1) / SKV_TILE;
+    const int tpb = T >= 1024 ? 8 : T >= 256 ? 4 : 1;   // per-workgroup finals cost O(T): amortise them for long contexts
+    const int gx = (T + tpb - 1) / tpb;
 #define SKV_NG(GG)                                                                                              \
-    hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(T, B), dim3(256), 0, st, (const bf16_t*)D, pmax, \
-                       psum, (bf16_t*)P, (bf16_t*)score, N, T, score_stride)
+    hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)D, pmax, \
+                       psum, (bf16_t*)P, (bf16_t*)score, N, T, score_stride, tpb)
     switch (G) {
         case 1: SKV_NG(1); break;
         case 2: SKV_NG(2); break;
@@ -640,16 +662,16 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
     if (stage) {
         static size_t attr_bytes = 0;
         if (smem > 64 * 1024 && smem > attr_bytes) {
-            if (hipFuncSetAttribute((const void*)skv_topk_reorder_kernel<true>,
+            if (hipFuncSetAttribute((const void*)skv_topk_reorder_kernel<1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                 return SKV_ERR_LAUNCH;
             attr_bytes = 150 * 1024;
         }
-        hipLaunchKernelGGL(skv_topk_reorder_kernel<true>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
+        hipLaunchKernelGGL(skv_topk_reorder_kernel<1>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
                            (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, N,
                            score_stride, S, H, SP);
     } else {
-        hipLaunchKernelGGL(skv_topk_reorder_kernel<false>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
+        hipLaunchKernelGGL(skv_topk_reorder_kernel<0>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
                            (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, N,
                            score_stride, S, H, SP);
     }
