@@ -44,8 +44,6 @@ typedef void* skv_stream_t;
 SKV_EXPORT int skv_abi_version(void);
 /* text of the last HIP error seen by a launcher on this thread ("" if none) */
 SKV_EXPORT const char* skv_last_error(void);
-/* 1 if a row-mover spin ever timed out on the current device (results then invalid) */
-SKV_EXPORT int skv_move_timeout_flag(void);
 
 /* ------------------------------------------------------------------------------------------
  * Part 1: the `kernels.shadowkv` surface (functions.h line cited per entry)
@@ -64,17 +62,18 @@ SKV_EXPORT int skv_reorder_keys_and_compute_offsets(int64_t* cached_pos_ids, con
                                          skv_stream_t stream);
 
 /* functions.h:151  gather_copy_with_offsets(values, v_cache_buffer, temp, offsets, cnts, signals, ...)
- * `values` is pinned, device-mapped host memory.  `temp` is accepted and unused (no bounce buffer).
- * `signals` uint32[batch*heads], zero on entry, zero again on completion. */
+ * `values` is pinned, device-mapped host memory.  `temp` [batch][heads][map_size][1024] bf16 (the reference's bounce
+ * buffer, /root/reference/models/kv_cache.py:612-620) stages the hit rows that move: two launches (stage, land), no
+ * inter-workgroup hand-off.  `signals` is accepted and never touched (the reference's 2-CTA flag, copy.cuh:250-263). */
 SKV_EXPORT int skv_gather_copy_with_offsets(const void* values, void* v_cache_buffer, void* temp, const int32_t* offsets,
                                  const int32_t* cnts, uint32_t* signals, int batch_size, int heads,
                                  int cpu_v_length, int gpu_v_length, int gpu_v_offset, int gpu_v_stride,
                                  int map_size, skv_stream_t stream);
 
 /* functions.h:97  gather_copy_d2d_with_offsets(keys, offsets, cnts, bs, heads, gpu_k_length, gpu_k_offset,
- * gpu_k_stride, map_size).  Extra argument `signals` (same contract as above): the reference serialises a
- * (batch, head) inside one CTA, this library spreads it over a team of workgroups. */
-SKV_EXPORT int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, uint32_t* signals,
+ * gpu_k_stride, map_size).  Extra argument `temp` (staging, sized as above): the reference serialises a
+ * (batch, head) inside one CTA; this library spreads it over map_size/8 workgroups of two launches. */
+SKV_EXPORT int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, void* temp,
                                      int batch_size, int heads, int gpu_k_length, int gpu_k_offset,
                                      int gpu_k_stride, int map_size, skv_stream_t stream);
 
@@ -161,14 +160,6 @@ SKV_EXPORT int skv_select_chunks(const void* q, const void* landmarks, const int
 SKV_EXPORT int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
                         int blocks, int groups, int n_landmarks, float alpha, skv_stream_t stream);
 
-/* ShadowKVCache_CPU.get_value_cache (kv_cache.py:1059-1106): compaction of hit chunks + fetch of miss
- * chunks from the pinned host table into the sparse region.  Strides / offsets in bf16 elements.
- * host_values == NULL: compaction only (this is also the K-side compaction of get_key_cache,
- * kv_cache.py:1140-1150). */
-SKV_EXPORT int skv_move_chunks(const void* host_values, void* cache_buffer, const int32_t* offsets, const int32_t* cnts,
-                    uint32_t* signals, long long host_block_stride, long long cache_block_stride,
-                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream);
-
 /* ShadowKVCache_CPU.get_key_cache, rebuild part (kv_cache.py:1157-1168 -> models/tensor_op.py:201-238):
  * k_cache[b][h][sparse_start + i][:] = RoPE(bf16(U[b][pos(i)] . SV[b][h]^T), pos(i)) for chunks >= cnts.
  * chunk_ids int64 [bs][heads][select_sets] (the reordered cached_pos_ids); rope_mode 1 = Llama
@@ -181,7 +172,8 @@ SKV_EXPORT int skv_rebuild_keys(const void* U, const void* SV, const void* cos_s
                      int sparse_start, int rope_mode, const void* hit_temp, const int32_t* hit_offsets,
                      skv_stream_t stream);
 
-/* Two-phase, spin-free form of skv_move_chunks used by the decode path:
+/* ShadowKVCache_CPU.get_value_cache (kv_cache.py:1059-1106) / the K-side compaction of get_key_cache (:1140-1150) as the
+ * decode path launches them - two phases, no in-kernel synchronisation:
  *   skv_stage_hit_chunks: temp[b][i] <- cache[b][sparse + offsets[i]] for hit chunks whose slot changes, for
  *                         the K and the V buffer in one launch (either may be NULL);
  *   skv_land_chunks     : cache[b][sparse + i] <- temp[b][i] (moved hits) / host_values[b][offsets[i]] (misses;
@@ -208,11 +200,13 @@ SKV_EXPORT int skv_fetch_kv(const void* U, const void* SV, const void* cos_sin, 
 
 /* Sparse decode attention (replaces flash_attn_with_kvcache at /root/reference/models/base.py:341 for
  * q_len == 1).  q [bs][q_heads][128], k/v [bs][kv_heads][rows][128] (kv_head_stride elements between heads),
- * out [bs][q_heads][128] bf16.  kv_len_dev (int32 on device) overrides kv_len when non-NULL.
+ * out [bs][q_heads][128] bf16.  kv_len_dev (int32 on device) overrides kv_len when non-NULL; kv_rows = rows a head
+ * owns in k / v: a host kv_len beyond it is SKV_ERR_ARG, a device-side one is clamped to it (the reference's view slice
+ * [:sparse_end + gen] clamps the same way, /root/reference/models/kv_cache.py:1100,1172).
  * workspace: skv_attn_workspace_bytes(bs, q_heads, splits). */
 SKV_EXPORT size_t skv_attn_workspace_bytes(int batch_size, int q_heads, int splits);
 SKV_EXPORT int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,
-                         const int32_t* kv_len_dev, int kv_len, long long kv_head_stride, int batch_size,
+                         const int32_t* kv_len_dev, int kv_len, int kv_rows, long long kv_head_stride, int batch_size,
                          int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -224,12 +218,14 @@ SKV_EXPORT int skv_sparse_attention(const void* q, const void* k, const void* v,
  * q and k at pos[b] (rope_mode 1 = NeoX / Llama, 2 = GLM), write q [bs][q_heads][128] and push k, v into
  * row *row_idx of the cache buffers [bs][kv_heads][cache_rows][128].  Replaces vllm rotary_embedding
  * (/root/reference/models/llama.py:296) + ShadowKVCache_CPU.update_kv_cache (kv_cache.py:1227-1271); rows
- * outside [0, cache_rows) are dropped like the reference's zero-length slice.  q_override (nullable): values
- * written to q instead of the rotated projection (synthetic-query benchmarking). */
+ * outside [0, cache_rows) are dropped like the reference's zero-length slice; pos[b] is clamped to the cos_sin_rows
+ * rows of the table.  q_override (nullable): values written to q instead of the rotated projection (synthetic-query
+ * benchmarking). */
 SKV_EXPORT int skv_qkv_rope_update(const void* qkv, const void* cos_sin, const int64_t* pos, const int64_t* row_idx,
                         const void* q_override, void* q_out, void* k_cache, void* v_cache, int batch_size,
-                        int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, long long cache_stride_b,
-                        long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
+                        int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, int cos_sin_rows,
+                        long long cache_stride_b, long long cache_stride_h, int cache_rows, int rope_mode,
+                        skv_stream_t stream);
 
 /* h = x + residual (bf16; residual may be NULL), y = RMSNorm(h) * weight (flashinfer.norm.rmsnorm,
  * /root/reference/models/tensor_op.py:34-39).  h_out nullable. */
@@ -264,7 +260,7 @@ SKV_EXPORT int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
 SKV_EXPORT int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const void* residual, const void* norm_weight,
                              float eps, void* h_out, const void* bias, const void* cos_sin, const int64_t* pos,
                              const int64_t* row_idx, const void* q_override, void* q_out, void* k_cache, void* v_cache,
-                             int K, int q_heads, int kv_heads, int head_dim, long long cos_sin_stride,
+                             int K, int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, int cos_sin_rows,
                              long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream);
 
 /* ---- part 3b: in-place chunk layout (MI355X-first variant of parts 1-2) ---------------------------------------- */
@@ -299,7 +295,7 @@ SKV_EXPORT int skv_fetch_kv_inplace(const void* U, const void* SV, const void* c
 SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
-                              int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
                               int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, float scale, skv_stream_t stream);
@@ -313,8 +309,9 @@ SKV_EXPORT int skv_attn_finish_inplace(const void* q, const void* k_cache, const
 
 /* End of a decode step in one launch: top-p filter over the k <= 64 sorted top-k logits (vals = logits / temperature,
  * descending; idx their token ids), multinomial draw (sample_token, /root/reference/models/tensor_op.py:242-297) written
- * to token[bs], and the device-side step counters advanced: pos[b] += 1; gen = (gen + 1) % slack; row_idx = gen + base;
- * kv_len = row_idx + 1; step_idx = (step_idx + 1) % table_len (step_idx nullable).  Randomness: counter-based hash of
+ * to token[bs], and the device-side step counters advanced: pos[b] += 1; gen += 1 (tokens generated so far); row_idx =
+ * base + gen % slack; kv_len = base + min(gen + 1, slack); step_idx = (step_idx + 1) % table_len (step_idx nullable).
+ * (gen < slack is the regular case; beyond it the generated rows are a ring of the last `slack` tokens.)  Randomness: counter-based hash of
  * (seed, pos[b], b, lane) - reproducible and graph-capturable. */
 SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,
                        unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,

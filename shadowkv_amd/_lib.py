@@ -23,7 +23,6 @@ _ROPE_PUSH = [c_p] * 5 + [c_int] * 19 + [c_p]
 _SIGS = {
     "skv_abi_version": (c_int, []),
     "skv_last_error": (ctypes.c_char_p, []),
-    "skv_move_timeout_flag": (c_int, []),
     "skv_batch_gemm_softmax": (c_int, [c_p] * 6 + [c_int] * 4 + [c_f, c_f, c_p]),
     "skv_reorder_keys_and_compute_offsets": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),
     "skv_gather_copy_with_offsets": (c_int, [c_p] * 6 + [c_int] * 7 + [c_p]),
@@ -40,25 +39,24 @@ _SIGS = {
     "skv_select_chunks": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f, c_p]),
     "skv_select_chunks_inplace": (c_int, [c_p] * 10 + [c_int] * 4 + [c_f, c_p]),
     "skv_fetch_kv_inplace": (c_int, [c_p] * 9 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
-    "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 9 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_f, c_p]),
+    "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 10 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_f, c_p]),
     "skv_attn_finish_inplace": (c_int, [c_p] * 7 + [c_int] * 4 + [c_ll] + [c_int] * 2 + [c_f, c_p]),
     "skv_sample_advance": (c_int, [c_p] * 2 + [c_int] * 2 + [c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
-    "skv_move_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
     "skv_fetch_kv": (c_int, [c_p] * 11 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
     "skv_stage_hit_chunks": (c_int, [c_p] * 6 + [c_ll] * 2 + [c_int] * 2 + [c_p]),
     "skv_land_chunks": (c_int, [c_p] * 5 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
     "skv_attn_workspace_bytes": (c_sz, [c_int] * 3),
-    "skv_qkv_rope_update": (c_int, [c_p] * 8 + [c_int] * 4 + [c_ll] * 3 + [c_int] * 2 + [c_p]),
+    "skv_qkv_rope_update": (c_int, [c_p] * 8 + [c_int] * 4 + [c_ll, c_int] + [c_ll] * 2 + [c_int] * 2 + [c_p]),
     "skv_add_rmsnorm": (c_int, [c_p] * 5 + [c_int] * 2 + [c_f, c_p]),
     "skv_silu_and_mul": (c_int, [c_p] * 2 + [c_int] * 2 + [c_p]),
     "skv_norm_gemv_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 3 + [c_int] * 3 + [c_p]),
-    "skv_qkv_gemv_rope_update": (c_int, [c_p] * 4 + [c_f] + [c_p] * 9 + [c_int] * 4 + [c_ll] * 2 + [c_int] * 2 + [c_p]),
+    "skv_qkv_gemv_rope_update": (c_int, [c_p] * 4 + [c_f] + [c_p] * 9 + [c_int] * 4 + [c_ll, c_int, c_ll] + [c_int] * 2 + [c_p]),
     "skv_gemv_bf16": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),
     "skv_chunk_stats": (c_int, [c_p, c_ll] + [c_int] * 4 + [c_p] * 3),
     "skv_linear_rows_bf16": (c_int, [c_p] * 4 + [c_int] * 4 + [c_p]),
-    "skv_sparse_attention": (c_int, [c_p] * 6 + [c_int, c_ll] + [c_int] * 5 + [c_f, c_p]),
+    "skv_sparse_attention": (c_int, [c_p] * 6 + [c_int, c_int, c_ll] + [c_int] * 5 + [c_f, c_p]),
 }
 
 EXPORTS = tuple(_SIGS)

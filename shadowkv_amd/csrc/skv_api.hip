@@ -17,9 +17,9 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st);
-int skv_launch_move_rows(const void* host_rows, void* dev, const int32_t* offsets, const int32_t* cnts,
-                         unsigned int* signals, long long host_len_elems, long long dev_stride_elems,
-                         long long dev_off_elems, int B, int S, hipStream_t st);
+int skv_launch_move_rows(const void* host_rows, void* dev, void* temp, const int32_t* offsets, const int32_t* cnts,
+                         long long host_len_elems, long long dev_stride_elems, long long dev_off_elems, int B, int S,
+                         hipStream_t st);
 int skv_launch_gather_rows(const void* host_rows, void* dev, const int64_t* ids, long long host_len_elems,
                            long long dev_len_elems, int B, int S, hipStream_t st);
 int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const void* ids, int ids64,
@@ -39,7 +39,7 @@ int skv_launch_land_rows(const void* host_rows, void* buf, const void* temp, con
                          const int32_t* cnts, long long host_len_elems, long long stride_elems, long long off_elems,
                          int B, int S, hipStream_t st);
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
-                                const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
+                                const int* kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h, int bs, int Hq,
                                 int Hkv, int head_dim, int splits, float scale, hipStream_t st);
 int skv_launch_rope_chunked(const void* x, const void* cos_sin, const int32_t* pid, void* out, const int32_t* cnts,
                             int batch, int heads, int seq_len, int embed_dim, long long sxb, long long sxh,
@@ -120,19 +120,19 @@ int skv_gather_copy_with_offsets(const void* values, void* v_cache_buffer, void*
                                  const int32_t* cnts, uint32_t* signals, int batch_size, int heads,
                                  int cpu_v_length, int gpu_v_length, int gpu_v_offset, int gpu_v_stride,
                                  int map_size, skv_stream_t stream) {
-    (void)temp;
+    (void)signals;   // nothing spins: the launch boundary between stage and land is the only ordering
     (void)gpu_v_length;
-    if (!values || !v_cache_buffer || !offsets || !cnts || !signals) return SKV_ERR_ARG;
-    return finish(skv_launch_move_rows(values, v_cache_buffer, offsets, cnts, signals, cpu_v_length, gpu_v_stride,
+    if (!values || !v_cache_buffer || !temp || !offsets || !cnts) return SKV_ERR_ARG;
+    return finish(skv_launch_move_rows(values, v_cache_buffer, temp, offsets, cnts, cpu_v_length, gpu_v_stride,
                                        gpu_v_offset, batch_size * heads, map_size, (hipStream_t)stream));
 }
 
-int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, uint32_t* signals,
+int skv_gather_copy_d2d_with_offsets(void* keys, const int32_t* offsets, const int32_t* cnts, void* temp,
                                      int batch_size, int heads, int gpu_k_length, int gpu_k_offset,
                                      int gpu_k_stride, int map_size, skv_stream_t stream) {
     (void)gpu_k_length;
-    if (!keys || !offsets || !cnts || !signals) return SKV_ERR_ARG;
-    return finish(skv_launch_move_rows(nullptr, keys, offsets, cnts, signals, 0, gpu_k_stride, gpu_k_offset,
+    if (!keys || !offsets || !cnts || !temp) return SKV_ERR_ARG;
+    return finish(skv_launch_move_rows(nullptr, keys, temp, offsets, cnts, 0, gpu_k_stride, gpu_k_offset,
                                        batch_size * heads, map_size, (hipStream_t)stream));
 }
 
@@ -277,15 +277,6 @@ int skv_score_landmarks(const void* q, const void* landmarks, void* logits, floa
                                    (hipStream_t)stream));
 }
 
-int skv_move_chunks(const void* host_values, void* cache_buffer, const int32_t* offsets, const int32_t* cnts,
-                    uint32_t* signals, long long host_block_stride, long long cache_block_stride,
-                    long long cache_sparse_offset, int blocks, int select_sets, skv_stream_t stream) {
-    if (!cache_buffer || !offsets || !cnts || !signals) return SKV_ERR_ARG;
-    return finish(skv_launch_move_rows(host_values, cache_buffer, offsets, cnts, signals, host_block_stride,
-                                       cache_block_stride, cache_sparse_offset, blocks, select_sets,
-                                       (hipStream_t)stream));
-}
-
 int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,
                      const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
                      int rank, int select_sets, int chunk_size, long long cos_sin_stride,
@@ -334,7 +325,7 @@ int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, con
 int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
-                              int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
                               int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, float scale, skv_stream_t stream) {
@@ -342,7 +333,7 @@ int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin
         !attn_workspace)
         return SKV_ERR_ARG;
     if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
-    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, q_heads / heads, attn_splits, attn_splits, scale};
+    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits, scale};
     return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
@@ -378,10 +369,10 @@ int skv_land_chunks(const void* host_values, void* cache_buffer, const void* tem
 }
 
 int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,
-                         const int32_t* kv_len_dev, int kv_len, long long kv_head_stride, int batch_size,
+                         const int32_t* kv_len_dev, int kv_len, int kv_rows, long long kv_head_stride, int batch_size,
                          int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream) {
     if (!q || !k || !v || !out || !workspace) return SKV_ERR_ARG;
-    return finish(skv_launch_sparse_attention(q, k, v, out, workspace, kv_len_dev, kv_len, kv_head_stride,
+    return finish(skv_launch_sparse_attention(q, k, v, out, workspace, kv_len_dev, kv_len, kv_rows, kv_head_stride,
                                               batch_size, q_heads, kv_heads, head_dim, splits, scale,
                                               (hipStream_t)stream));
 }

@@ -23,10 +23,11 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
     const bf16_t* __restrict__ v,
     float* __restrict__ ws,         // [bs*Hkv][G][splits][AT_REC]  (acc[128], m, l)
-    const int* __restrict__ kv_len_dev, int kv_len_host, long long kv_stride_h /*elements*/, int Hkv, int splits,
-    float scale) {
+    const int* __restrict__ kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h /*elements*/, int Hkv,
+    int splits, float scale) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int kv_len = kv_len_dev ? *kv_len_dev : kv_len_host;
+    // never past the rows a head owns (the reference's view slice [:sparse_end + gen] clamps the same way)
+    const int kv_len = min(kv_len_dev ? *kv_len_dev : kv_len_host, kv_rows);
     skv_attn_partial_body<G, false>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
                                     nullptr, 0, 0, 0);
 }
@@ -206,9 +207,11 @@ int skv_launch_attn_finish(const void* q, const void* k, const void* v, const vo
 extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return (size_t)bs * Hq * splits * AT_REC * sizeof(float); }
 
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
-                                const int* kv_len_dev, int kv_len_host, long long kv_stride_h, int bs, int Hq,
+                                const int* kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h, int bs, int Hq,
                                 int Hkv, int head_dim, int splits, float scale, hipStream_t st) {
     if (head_dim != AT_D || Hkv < 1 || Hq % Hkv != 0 || splits < 1) return SKV_ERR_UNSUPPORTED;
+    if (kv_rows < 1 || (long long)kv_rows * AT_D > kv_stride_h || (!kv_len_dev && (kv_len_host < 1 || kv_len_host > kv_rows)))
+        return SKV_ERR_ARG;
     const int G = Hq / Hkv;
     dim3 grid(splits, bs * Hkv), block(256);
     const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float);
@@ -221,8 +224,8 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
             attr_set = true;                                                                                    \
         }                                                                                                       \
         hipLaunchKernelGGL((skv_attn_partial_kernel<GG>), grid, block, smem, st, (const bf16_t*)q,              \
-                           (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_stride_h, \
-                           Hkv, splits, scale);                                                                 \
+                           (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows,  \
+                           kv_stride_h, Hkv, splits, scale);                                                                 \
     } while (0)
     switch (G) {
         case 1: SKV_AT(1); break;

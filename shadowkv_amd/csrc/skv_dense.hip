@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void skv_qkv_rope_update_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos_sin, const int64_t* __restrict__ pos /*[bs]*/,
     const int64_t* __restrict__ row_idx /*[1]*/, const bf16_t* __restrict__ q_override /*nullable [bs][Hq][128]*/,
     bf16_t* __restrict__ q_out /*[bs][Hq][128]*/, bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache,
-    int Hq, int Hkv, long long cs_stride, long long cache_stride_b, long long cache_stride_h, int cache_rows) {
+    int Hq, int Hkv, long long cs_stride, int cs_rows, long long cache_stride_b, long long cache_stride_h, int cache_rows) {
     const int b = blockIdx.y, head = blockIdx.x, t = threadIdx.x;
     const bf16_t* x = qkv + ((size_t)b * (Hq + 2 * Hkv) + head) * 128;
     const long long row = *row_idx;
@@ -31,7 +31,9 @@ __global__ __launch_bounds__(64) void skv_qkv_rope_update_kernel(
         }
         return;
     }
-    const bf16_t* cs = cos_sin + pos[b] * cs_stride;
+    // the host refuses to step past the table (DecoderLM / GraphDecoder); the clamp keeps a stale counter in bounds
+    const long long p = min(max(pos[b], 0ll), (long long)cs_rows - 1);
+    const bf16_t* cs = cos_sin + p * cs_stride;
     float o1, o2;
     int i1, i2;
     if (!GLM) {
@@ -142,21 +144,22 @@ extern "C" {
 
 int skv_qkv_rope_update(const void* qkv, const void* cos_sin, const int64_t* pos, const int64_t* row_idx,
                         const void* q_override, void* q_out, void* k_cache, void* v_cache, int batch_size,
-                        int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, long long cache_stride_b,
-                        long long cache_stride_h, int cache_rows, int rope_mode, skv_stream_t stream) {
-    if (!qkv || !cos_sin || !pos || !row_idx || !q_out || !k_cache || !v_cache) return SKV_ERR_ARG;
+                        int q_heads, int kv_heads, int head_dim, long long cos_sin_stride, int cos_sin_rows,
+                        long long cache_stride_b, long long cache_stride_h, int cache_rows, int rope_mode,
+                        skv_stream_t stream) {
+    if (!qkv || !cos_sin || !pos || !row_idx || !q_out || !k_cache || !v_cache || cos_sin_rows < 1) return SKV_ERR_ARG;
     if (head_dim != 128 || (rope_mode != 1 && rope_mode != 2)) return SKV_ERR_UNSUPPORTED;
     dim3 grid(q_heads + 2 * kv_heads, batch_size);
     if (rope_mode == 1)
         hipLaunchKernelGGL(skv_qkv_rope_update_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qkv,
                            (const bf16_t*)cos_sin, pos, row_idx, (const bf16_t*)q_override, (bf16_t*)q_out,
-                           (bf16_t*)k_cache, (bf16_t*)v_cache, q_heads, kv_heads, cos_sin_stride, cache_stride_b,
-                           cache_stride_h, cache_rows);
+                           (bf16_t*)k_cache, (bf16_t*)v_cache, q_heads, kv_heads, cos_sin_stride, cos_sin_rows,
+                           cache_stride_b, cache_stride_h, cache_rows);
     else
         hipLaunchKernelGGL(skv_qkv_rope_update_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qkv,
                            (const bf16_t*)cos_sin, pos, row_idx, (const bf16_t*)q_override, (bf16_t*)q_out,
-                           (bf16_t*)k_cache, (bf16_t*)v_cache, q_heads, kv_heads, cos_sin_stride, cache_stride_b,
-                           cache_stride_h, cache_rows);
+                           (bf16_t*)k_cache, (bf16_t*)v_cache, q_heads, kv_heads, cos_sin_stride, cos_sin_rows,
+                           cache_stride_b, cache_stride_h, cache_rows);
     return finish_launch();
 }
 

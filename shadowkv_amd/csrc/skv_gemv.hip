@@ -32,7 +32,7 @@ struct QkvEpilogue {
     bf16_t* k_cache;          // [Hkv][cache_rows][128]
     bf16_t* v_cache;
     long long cs_stride, cache_stride_h;
-    int Hq, Hkv, cache_rows, glm;
+    int Hq, Hkv, cache_rows, glm, cs_rows;
 };
 
 template <int R, bool SILU_PAIR, bool NORM, bool QKV>
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
                     for (int r = 0; r < R; ++r) dst[rows[r] - head * 128] = f2bf(o[r]);
                 }
             } else {
-                const bf16_t* cs = qe.cos_sin + (*qe.pos) * qe.cs_stride;
+                const long long pcl = min(max(*qe.pos, 0ll), (long long)qe.cs_rows - 1);   // see skv_dense.hip
+                const bf16_t* cs = qe.cos_sin + pcl * qe.cs_stride;
                 float res[R];
                 int dim[R];
 #pragma unroll
@@ -318,12 +319,12 @@ extern "C" int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const v
                                         float eps, void* h_out, const void* bias, const void* cos_sin, const int64_t* pos,
                                         const int64_t* row_idx, const void* q_override, void* q_out, void* k_cache,
                                         void* v_cache, int K, int q_heads, int kv_heads, int head_dim,
-                                        long long cos_sin_stride, long long cache_stride_h, int cache_rows, int rope_mode,
-                                        skv_stream_t stream) {
-    if (!cos_sin || !pos || !row_idx || !q_out || !k_cache || !v_cache) return SKV_ERR_ARG;
+                                        long long cos_sin_stride, int cos_sin_rows, long long cache_stride_h, int cache_rows,
+                                        int rope_mode, skv_stream_t stream) {
+    if (!cos_sin || !pos || !row_idx || !q_out || !k_cache || !v_cache || cos_sin_rows < 1) return SKV_ERR_ARG;
     if (head_dim != 128 || (rope_mode != 1 && rope_mode != 2)) return SKV_ERR_UNSUPPORTED;
     QkvEpilogue qe{(const bf16_t*)cos_sin, pos, row_idx, (const bf16_t*)q_override, (bf16_t*)q_out, (bf16_t*)k_cache,
-                   (bf16_t*)v_cache, cos_sin_stride, cache_stride_h, q_heads, kv_heads, cache_rows, rope_mode == 2};
+                   (bf16_t*)v_cache, cos_sin_stride, cache_stride_h, q_heads, kv_heads, cache_rows, rope_mode == 2, cos_sin_rows};
     return launch_gemv(Wqkv, x, bias, nullptr, (q_heads + 2 * kv_heads) * 128, K, 0, residual, norm_weight, h_out, eps,
                        norm_weight != nullptr, (hipStream_t)stream, &qe);
 }

@@ -7,6 +7,7 @@ struct AttnLaunch {
     void* ws;                // attention workspace, rec_splits records per query head
     const int* kv_len_dev;   // nullable
     int kv_len_host;
+    int kv_rows;             // rows a head owns in the cache buffers: the device-side kv_len is clamped to it
     int G, splits, rec_splits;
     float scale;
 };

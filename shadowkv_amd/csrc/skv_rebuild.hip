@@ -44,7 +44,7 @@ struct AttnRole {
     const bf16_t* q;          // [bs][Hq][128]
     float* ws;                // [bs*Hq][rec_splits][AT_REC]
     const int* kv_len_dev;    // nullable
-    int kv_len_host, splits, rec_splits;
+    int kv_len_host, kv_rows, splits, rec_splits;
     float scale;
 };
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     if constexpr (AG > 0) if ((int)blockIdx.x >= rebuild_tiles + land_blocks) {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
         const int bh3 = blockIdx.y, cnt3 = cnts ? cnts[bh3] : 0;
-        const int kv_len = ar.kv_len_dev ? *ar.kv_len_dev : ar.kv_len_host;
+        const int kv_len = min(ar.kv_len_dev ? *ar.kv_len_dev : ar.kv_len_host, ar.kv_rows);
         skv_attn_partial_body<AG, true>(
             ar.q, out, reinterpret_cast<const bf16_t*>(v_buf), ar.ws, kv_len, out_stride_h, ar.splits, ar.rec_splits,
             (int)blockIdx.x - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
         const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
         evalid[it] = (i < total_rows) && (i >= cnt * C);
         if (MODE != 0 && evalid[it]) {
-            const long long p = chunk_id_at(ids, ids64, (size_t)bh * S + i / C) * C + i % C;
+            long long p = chunk_id_at(ids, ids64, (size_t)bh * S + i / C) * C + i % C;
+            if (p < 0 || p >= seq_len) p = 0;   // invalid ids are a caller error; never read outside the table
             const bf16_t* cs = cos_sin + p * cs_stride;
             if (MODE == 1) {
                 ecos[it] = *reinterpret_cast<const u32x4*>(cs + 8 * c);
@@ -302,8 +303,11 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
             attn->rec_splits < attn->splits || v_stride != out_stride_h || out_stride_s != RB_D ||
             out_stride_b != (long long)heads * out_stride_h || v_off != (long long)out_row0 * RB_D)
             return SKV_ERR_UNSUPPORTED;
-        ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->splits,
-                      attn->rec_splits, attn->scale};
+        if (attn->kv_rows < out_row0 + S * C || (long long)attn->kv_rows * RB_D > out_stride_h ||
+            (!attn->kv_len_dev && (attn->kv_len_host < 1 || attn->kv_len_host > attn->kv_rows)))
+            return SKV_ERR_ARG;
+        ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->kv_rows,
+                      attn->splits, attn->rec_splits, attn->scale};
         attn_g = attn->G;
         const size_t need = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float) + 32 * sizeof(uint32_t);
         if (need > smem_all) smem_all = need;

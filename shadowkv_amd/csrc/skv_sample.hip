@@ -50,11 +50,11 @@ __global__ __launch_bounds__(64) void skv_sample_advance_kernel(
     if (lane == win) token[b] = idx[(size_t)b * k + lane];
     if (lane == 0) {
         pos[b] = p0 + 1;
-        if (b == 0) {                                     // generated-row slack wraps like GraphDecoder's host mirror
-            const long long g2 = (gen[0] + 1) % slack;
-            gen[0] = g2;
-            row_idx[0] = g2 + base;
-            kv_len[0] = (int32_t)(g2 + base + 1);
+        if (b == 0) {                                     // gen counts generated tokens; past the slack the rows form a
+            const long long g2 = gen[0] + 1;              // ring of the last `slack` tokens (GraphDecoder: benchmarks only,
+            gen[0] = g2;                                  // the host refuses to step there otherwise)
+            row_idx[0] = base + g2 % slack;
+            kv_len[0] = (int32_t)(base + (g2 + 1 < slack ? g2 + 1 : slack));
             if (step_idx) step_idx[0] = (step_idx[0] + 1) % table_len;
         }
     }

@@ -14,7 +14,7 @@ import torch
 
 from .._lib import lib, check, ptr, current_stream_handle
 
-_signals = {}
+_staging = {}
 
 
 def _bf16(t, name, device_ok=("cuda",)):
@@ -29,12 +29,15 @@ def _dt(t, dtype, name):
     return t
 
 
-def _d2d_signals(device, blocks):
-    key = (device.type, device.index)
-    s = _signals.get(key)
-    if s is None or s.numel() < blocks:
-        s = torch.zeros(max(blocks, 4096), dtype=torch.int32, device=device)
-        _signals[key] = s
+def _d2d_staging(device, rows):
+    """Staging rows (2 KiB each) for the hit chunks gather_copy_d2d_with_offsets moves; the reference's signature has
+    no bounce buffer for the K side (one CTA per (batch, head) serialises it, copy.cuh:649-687).  Per (device, stream):
+    two streams may compact concurrently."""
+    key = (device.type, device.index, current_stream_handle())
+    s = _staging.get(key)
+    if s is None or s.shape[0] < rows:
+        s = torch.empty(rows, 1024, dtype=torch.bfloat16, device=device)
+        _staging[key] = s
     return s
 
 
@@ -49,8 +52,8 @@ def gather_copy_d2d_with_offsets(keys, offsets, cnts, batch_size, heads, gpu_k_l
                                  gpu_k_stride, map_size):
     """functions.h:97 -- in-place compaction of the hit rows of the key cache's sparse region."""
     _bf16(keys, "keys"); _dt(offsets, torch.int32, "offsets"); _dt(cnts, torch.int32, "cnts")
-    sig = _d2d_signals(keys.device, batch_size * heads)
-    check(lib().skv_gather_copy_d2d_with_offsets(ptr(keys), ptr(offsets), ptr(cnts), ptr(sig), batch_size, heads,
+    tmp = _d2d_staging(keys.device, batch_size * heads * map_size)
+    check(lib().skv_gather_copy_d2d_with_offsets(ptr(keys), ptr(offsets), ptr(cnts), ptr(tmp), batch_size, heads,
                                                  gpu_k_length, gpu_k_offset, gpu_k_stride, map_size,
                                                  current_stream_handle()), "gather_copy_d2d_with_offsets")
 
@@ -66,8 +69,11 @@ def reorder_keys_and_compute_offsets(cached_pos_ids, cur_pos_ids, offsets, cnts,
 
 def gather_copy_with_offsets(values, v_cache_buffer, temp, offsets, cnts, signals, batch_size, heads,
                              cpu_v_length, gpu_v_length, gpu_v_offset, gpu_v_stride, map_size):
-    """functions.h:151 -- hit rows compacted in place, miss rows fetched from pinned host memory."""
-    _bf16(values, "values"); _bf16(v_cache_buffer, "v_cache_buffer")
+    """functions.h:151 -- hit rows compacted in place, miss rows fetched from pinned host memory.  `temp` must hold
+    batch_size * heads * map_size rows of 1024 bf16 (the reference's size, kv_cache.py:612-620)."""
+    _bf16(values, "values"); _bf16(v_cache_buffer, "v_cache_buffer"); _bf16(temp, "temp")
+    if temp.numel() < batch_size * heads * map_size * 1024:
+        raise ValueError(f"temp: {temp.numel()} elements, need {batch_size * heads * map_size * 1024}")
     _dt(offsets, torch.int32, "offsets"); _dt(cnts, torch.int32, "cnts"); _dt(signals, torch.int32, "signals")
     check(lib().skv_gather_copy_with_offsets(ptr(values), ptr(v_cache_buffer), ptr(temp), ptr(offsets), ptr(cnts),
                                              ptr(signals), batch_size, heads, cpu_v_length, gpu_v_length,

@@ -164,16 +164,16 @@ class ShadowKVCache_CPU:
         self.block_num = bs * kv
         self.offsets = torch.zeros(self.block_num * self.select_sets, device=self.device, dtype=torch.int32)
         self.cnts = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
-        self.signals = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
-        self._signals_k = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
+        self.signals = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)   # reference attribute; unused
         self.position_ids = torch.full((L, bs, kv, self.select_sets), -1, device=self.device, dtype=torch.int64)
-        # kept for signature compatibility with the reference's kernels (unused by the fused path)
-        self.temp = torch.zeros(1, device=self.device, dtype=dtype)
-        self.output = torch.zeros(1, device=self.device, dtype=dtype)
         self._select_ws = None
-        # staging buffers of the two-phase (spin-free) chunk movement: moved hit chunks of one layer
+        # staging buffers of the two-phase (spin-free) chunk movement: moved hit chunks of one layer.  `temp` is the
+        # reference's attribute of the same shape (kv_cache.py:612-620) and IS the V staging buffer; `output` is the
+        # pre-RoPE K scratch of the reference's two-launch key path (kv_cache.py:637-645), unused by the fused path.
         self._temp_k = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
         self._temp_v = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
+        self.temp = self._temp_v.view(bs, kv, self.select_sets, C * D)
+        self.output = torch.zeros(bs, kv, self.sparse_budget, D, device=self.device, dtype=dtype)
         self._staged_layer = -1
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
         self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
@@ -198,6 +198,7 @@ class ShadowKVCache_CPU:
         self.gen_offset = 0
         self.prefill_local = 0
         self.prefilled_batch = 0
+        self._select_ws = None          # sized for the previous landmark count
 
     def H2D(self):
         """Reference: moves U / SV / landmarks / scratch from CPU tensors to the GPU (kv_cache.py:1178-1225).
@@ -444,6 +445,10 @@ class ShadowKVCache_CPU:
         like tensor_op.sparse_attention_decode; same values up to the order of the f32 sums."""
         if query_states.shape[-2] != 1:
             raise ValueError("decode-time selection expects q_len == 1")
+        buf_rows = self.k_cache_buffer.shape[-2]
+        if kv_len_dev is None and not self.sparse_end < int(kv_len) <= buf_rows:
+            raise ValueError(f"kv_len {kv_len} outside ({self.sparse_end}, {buf_rows}]: the generated-row slack is "
+                             f"{buf_rows - self.sparse_end} rows")
         self.incoming_q_len = 1
         lm = self.k_landmark[layer_idx]
         if self._select_ws is None:
@@ -467,7 +472,7 @@ class ShadowKVCache_CPU:
         scale = 1.0 / math.sqrt(D)
         check(L.skv_fetch_kv_attn_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
                                           ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), ptr(q), ptr(ws),
-                                          ptr(kv_len_dev), int(kv_len), U.shape[0], self.num_key_value_heads, Hq,
+                                          ptr(kv_len_dev), int(kv_len), buf_rows, U.shape[0], self.num_key_value_heads, Hq,
                                           U.shape[1], D, self.rank, self.select_sets, self.chunk_size,
                                           cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
                                           self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA, scale, st),
@@ -481,8 +486,16 @@ class ShadowKVCache_CPU:
     def note_kv_appended(self, incoming=1):
         """Bookkeeping half of update_kv_cache for callers that wrote the new K / V rows themselves
         (tensor_op.qkv_rope_update pushes them from the fused QKV kernel): advances the offsets once per token."""
+        slack = self.k_cache_buffer.shape[-2] - self.sparse_end
+        if self.gen_offset + incoming > slack:
+            raise RuntimeError(f"generated-row slack exhausted: {self.gen_offset} + {incoming} > {slack} rows after the "
+                               "sparse region (the reference silently drops such tokens, kv_cache.py:1255-1265)")
         self.kv_offset += incoming
         self.gen_offset += incoming
+
+    def generated_row_slack(self):
+        """Rows left for generated tokens behind the sparse region (buf_len - sparse_end; 96 at the 122K config)."""
+        return self.k_cache_buffer.shape[-2] - self.sparse_end - self.gen_offset
 
     def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
         """Appends the new token's K / V after the sparse region (kv_cache.py:1227-1271); rows past

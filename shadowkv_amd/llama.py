@@ -257,7 +257,15 @@ class DecoderLM:
             logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
         else:
             c = self.kv_cache
-            row = c.kv_offset if self.attn_mode == "full" else c.sparse_end + c.gen_offset
+            full = self.attn_mode == "full"
+            row = c.kv_offset if full else c.sparse_end + c.gen_offset
+            rows = (c.k_cache if full else c.k_cache_buffer).shape[-2]
+            if row >= rows:
+                raise RuntimeError(f"no cache row left for the new token (row {row} of {rows}): the generated-row slack "
+                                   "is exhausted; the reference silently drops such tokens (kv_cache.py:1255-1265)")
+            if c.kv_offset >= self.cos_sin_cache.shape[0]:
+                raise RuntimeError(f"position {c.kv_offset} is past the RoPE table ({self.cos_sin_cache.shape[0]} rows = "
+                                   "max_length + max_new_tokens)")
             pos = self.get_ctx(next_token)
             row_idx = torch.tensor([row], device=self.device, dtype=torch.long)
             logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table)
@@ -361,14 +369,20 @@ class GraphDecoder:
     launch sequence stays valid:
         token     int64 [bs,1]   input token (the previous step's sample is written back into it)
         pos       int64 [bs,1]   RoPE position of the new token            (= kv_cache.kv_offset)
-        row_idx   int64 [1]      buffer row the new K/V go to              (= sparse_end + gen_offset)
-        kv_len    int32 [1]      rows attended                              (= sparse_end + gen_offset + 1)
+        gen       int64 [1]      tokens generated so far                    (= kv_cache.gen_offset)
+        row_idx   int64 [1]      buffer row the new K/V go to              (= sparse_end + gen)
+        kv_len    int32 [1]      rows attended                              (= sparse_end + gen + 1)
         step      int64 [1]      index into the synthetic query table (bench only)
+    step() raises once the generated-row slack (buf_len - sparse_end rows, 96 at 122K) or the RoPE table is used up -
+    the reference silently drops such tokens (kv_cache.py:1255-1265).  `ring_slack=True` (benchmarks only, recorded in
+    the bench line) keeps stepping instead: the generated rows become a ring of the last `slack` tokens (row = gen %
+    slack, kv_len stays at its maximum), so every step does at least the work of the last in-range step.
     At bs = 1 a decode step is ~25 launches per layer; eager PyTorch is host-bound on that
     (MI355X_MICROARCH.md "graph-replay-floor"), the graph removes the per-launch host cost."""
 
-    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None, seed=1234):
+    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None, seed=1234, ring_slack=False):
         self.m = model
+        self.ring_slack = bool(ring_slack)
         self.seed = int(seed)
         self.temperature, self.top_p, self.top_k = temperature, top_p, top_k
         c = model.kv_cache
@@ -381,8 +395,9 @@ class GraphDecoder:
         self.token = torch.zeros(model.batch_size, 1, dtype=torch.long, device=dev)
         self.pos = torch.full((model.batch_size, 1), c.kv_offset, dtype=torch.long, device=dev)
         self.gen = torch.full((1,), gen0, dtype=torch.long, device=dev)
-        self.row_idx = self.gen + self.base
-        self.kv_len = (self.row_idx + 1).to(torch.int32)
+        self.gen_host = int(gen0)
+        self.row_idx = self.gen % self.slack + self.base
+        self.kv_len = (self.gen + 1).clamp(max=self.slack).add(self.base).to(torch.int32)
         self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
         self.walk_table = walk_table                     # [T, L, bs, Hq, 1, D] or None
         self._zero = torch.zeros((), device=dev, dtype=model.dtype)
@@ -441,19 +456,29 @@ class GraphDecoder:
                                            self.base, self.slack, tlen, current_stream_handle()), "sample_advance")
             return
         self.token.copy_(self._sample(last))
-        # advance the device-side counters (generated-row slack wraps like the host bookkeeping in step())
+        # advance the device-side counters (same arithmetic as skv_sample_advance)
         self.pos.add_(1)
-        self.gen.copy_((self.gen + 1) % self.slack)
-        self.row_idx.copy_(self.gen + self.base)
-        self.kv_len.copy_((self.row_idx + 1).to(torch.int32))
+        self.gen.add_(1)
+        self.row_idx.copy_(self.gen % self.slack + self.base)
+        self.kv_len.copy_((self.gen + 1).clamp(max=self.slack).add(self.base).to(torch.int32))
         if self.walk_table is not None:
             self.step_idx.copy_((self.step_idx + 1) % self.walk_table.shape[0])
 
     def _host_advance(self):
         c = self.m.kv_cache
         c.kv_offset += 1
+        self.gen_host += 1
         if not self.full:
-            c.gen_offset = (c.gen_offset + 1) % self.slack
+            c.gen_offset = min(self.gen_host, self.slack)
+
+    def _check_room(self):
+        c = self.m.kv_cache
+        if self.gen_host >= self.slack and not self.ring_slack:
+            raise RuntimeError(f"generated-row slack exhausted after {self.gen_host} tokens ({self.slack} rows behind the "
+                               "sparse region); GraphDecoder(ring_slack=True) is the benchmark-only way past it")
+        if c.kv_offset >= self.m.cos_sin_cache.shape[0]:
+            raise RuntimeError(f"position {c.kv_offset} is past the RoPE table ({self.m.cos_sin_cache.shape[0]} rows = "
+                               "max_length + max_new_tokens)")
 
     @torch.inference_mode()
     def capture(self, warmup=2):
@@ -461,6 +486,7 @@ class GraphDecoder:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):          # eager: sizes workspaces, sets kernel attributes, warms hipBLASLt
+                self._check_room()
                 self._body()
                 self._host_advance()
         torch.cuda.current_stream().wait_stream(s)
@@ -472,6 +498,7 @@ class GraphDecoder:
 
     @torch.inference_mode()
     def step(self):
+        self._check_room()
         if self.graph is None:
             self._body()
         else:

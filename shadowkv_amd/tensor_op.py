@@ -105,7 +105,8 @@ def qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_he
     q = torch.empty(bs, q_heads, 1, D, dtype=qkv.dtype, device=qkv.device)
     check(lib().skv_qkv_rope_update(ptr(qkv), ptr(cos_sin), ptr(pos), ptr(row_idx), ptr(q_override), ptr(q),
                                     ptr(k_cache), ptr(v_cache), bs, q_heads, kv_heads, D, cos_sin.stride(0),
-                                    k_cache.stride(0), k_cache.stride(1), k_cache.shape[2], 1 if width == 128 else 2,
+                                    cos_sin.shape[0], k_cache.stride(0), k_cache.stride(1), k_cache.shape[2],
+                                    1 if width == 128 else 2,
                                     current_stream_handle()), "qkv_rope_update")
     return q
 
@@ -125,8 +126,8 @@ def norm_qkv_rope_update(x, residual, norm_w, eps, wqkv, bqkv, cos_sin, pos, row
     check(lib().skv_qkv_gemv_rope_update(ptr(wqkv), ptr(x), ptr(residual), ptr(norm_w), float(eps),
                                          ptr(h) if residual is not None else 0, ptr(bqkv), ptr(cos_sin), ptr(pos),
                                          ptr(row_idx), ptr(q_override), ptr(q), ptr(k_cache), ptr(v_cache), K, q_heads,
-                                         kv_heads, D, cos_sin.stride(0), k_cache.stride(1), k_cache.shape[2],
-                                         1 if cos_sin.shape[-1] == 128 else 2, current_stream_handle()),
+                                         kv_heads, D, cos_sin.stride(0), cos_sin.shape[0], k_cache.stride(1),
+                                         k_cache.shape[2], 1 if cos_sin.shape[-1] == 128 else 2, current_stream_handle()),
           "qkv_gemv_rope_update")
     return h, q
 
@@ -235,8 +236,11 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     bs, Hq = q.shape[0], q.shape[1]
     D = q.shape[-1]
     Hkv = k_cache.shape[1]
+    rows = k_cache.shape[2]
     if kv_len is None:
-        kv_len = k_cache.shape[2]
+        kv_len = rows
+    if kv_len_dev is None and not 1 <= int(kv_len) <= rows:
+        raise ValueError(f"kv_len {kv_len} outside the {rows} rows of the cache view")
     if k_cache.stride(3) != 1 or k_cache.stride(2) != D or k_cache.stride(0) != Hkv * k_cache.stride(1) \
             or k_cache.stride() != v_cache.stride():
         raise ValueError("k/v cache views must be row-contiguous slices of [bs, Hkv, rows, D] buffers")
@@ -248,7 +252,7 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
     check(lib().skv_sparse_attention(ptr(q), ptr(k_cache), ptr(v_cache), ptr(out), ptr(ws), ptr(kv_len_dev),
-                                     int(kv_len), k_cache.stride(1), bs, Hq, Hkv, D, splits, 1.0 / math.sqrt(D),
+                                     int(kv_len), rows, k_cache.stride(1), bs, Hq, Hkv, D, splits, 1.0 / math.sqrt(D),
                                      current_stream_handle()), "sparse_attention")
     return out
 

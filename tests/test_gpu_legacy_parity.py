@@ -101,13 +101,13 @@ def test_gather_copy_with_offsets(sk, S, hit):
     oracle.gather_copy_with_offsets(host, b0, None, off, cnt, None, *args)
     hostp = host.pin_memory()
     b1 = buf.to(DEV); sig = torch.zeros(B, dtype=torch.int32, device=DEV)
-    temp = torch.zeros(1, dtype=torch.bfloat16, device=DEV)
+    temp = torch.zeros(B, S, 8 * D, dtype=torch.bfloat16, device=DEV)     # the reference's bounce buffer shape
     sk.gather_copy_with_offsets(hostp, b1, temp, off.to(DEV), cnt.to(DEV), sig, *args)
     torch.cuda.synchronize()
     assert_bits_equal(b0, b1, "V buffer after gather_copy_with_offsets")
     assert int(sig.abs().sum()) == 0, "signals must be zero on exit"
-    from shadowkv_amd._lib import lib
-    assert lib().skv_move_timeout_flag() == 0
+    with pytest.raises(ValueError):                                        # an undersized bounce buffer is refused
+        sk.gather_copy_with_offsets(hostp, b1, temp[:1, :1], off.to(DEV), cnt.to(DEV), sig, *args)
 
 
 @pytest.mark.parametrize("S,hit", [(256, 0.6), (256, 1.0), (128, 0.2)])
