@@ -154,6 +154,16 @@ SKV_EXPORT int skv_select_chunks(const void* q, const void* landmarks, const int
                       int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
                       int blocks, int groups, int n_landmarks, int select_sets, float alpha, skv_stream_t stream);
 
+/* The LAST stage of skv_select_chunks[_inplace] alone - what the reference does with torch.topk + gather +
+ * reorder_keys_and_compute_offsets (/root/reference/models/kv_cache.py:1031-1055): exact top-`select_sets` of the bf16
+ * scores (non-negative: softmax probabilities after the group max; ties at the k-th value -> lowest landmark slot),
+ * slot -> chunk id, diff against the resident set.  scores [blocks][score_stride] bf16, score_stride % 8 == 0 and
+ * >= n_landmarks, rows 16-B aligned.  dst_slots NULL: reference slot order (offsets = old slot / chunk id as in
+ * skv_select_chunks); non-NULL: in-place layout (offsets = miss ids, as in skv_select_chunks_inplace). */
+SKV_EXPORT int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                           int32_t* offsets, int32_t* dst_slots, int32_t* cnts, int64_t* selected_out, int blocks,
+                           int n_landmarks, int select_sets, skv_stream_t stream);
+
 /* Stage 1 of skv_select_chunks alone (the HBM-bound landmark scan), for roofline measurement and
  * profiling: logits bf16 [blocks][groups][n] and per-256-landmark partial (max, sum) f32
  * [blocks][ceil(n/256)][groups].  Same kernel, same launch shape as inside skv_select_chunks. */

@@ -270,6 +270,15 @@ int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_
                                           selected_out, dst_slots, blocks, n_landmarks, select_sets, st));
 }
 
+int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                           int32_t* offsets, int32_t* dst_slots, int32_t* cnts, int64_t* selected_out, int blocks,
+                           int n_landmarks, int select_sets, skv_stream_t stream) {
+    if (!scores || !cached_pos_ids || !offsets || !cnts) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
+    return finish(skv_launch_topk_reorder(scores, score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
+                                          selected_out, dst_slots, blocks, n_landmarks, select_sets, (hipStream_t)stream));
+}
+
 int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
                         int blocks, int groups, int n_landmarks, float alpha, skv_stream_t stream) {
     if (!q || !landmarks || !logits || !part_max || !part_sum || blocks < 1 || n_landmarks < 1) return SKV_ERR_ARG;

@@ -590,6 +590,304 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// K2b, second generation (default for N <= 131,072 scores per head): same results as the kernel above with a
+// shorter dependency chain (the kernel is latency-bound: 15 K scores over 1,024 threads are 15 per thread).
+//   * the thread's scores stay in registers (SEGV contiguous 16-B vectors per thread, loaded once);
+//   * ONE histogram pass finds the exact k-th value: 4,096 bins of the 16-bit pattern counted down from the head's
+//     maximum (32 binades; softmax scores of one head fit - otherwise the window slides and the pass repeats), two
+//     bins per word as 16-bit halves, 8 lane-private copies laid out [word][copy] so the copies of a bin sit in 8
+//     different banks.  Real rows spread over hundreds of these bins, so the serialisation that forced a 32-way
+//     privatised 256-bin histogram + a second pass above does not arise;
+//   * block scans keep one barrier (every wave re-scans the 16 wave totals itself), both counters of a scan are
+//     packed into one integer.
+// ---------------------------------------------------------------------------------------
+#define T2_THREADS 1024
+#define T2_BINS 4096
+#define T2_COPIES 8
+
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// inclusive scan over the 1,024-thread workgroup, ONE barrier: each wave publishes its total, then re-scans the 16
+// totals on its own lanes 0..15 (DPP row scan) and picks its prefix with a readlane.  s_w[16] must not be rewritten
+// before another barrier.
+__device__ __forceinline__ int block_scan_incl1(int v, int* s_w, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    v = wave_scan_incl(v);
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    int w = lane < 16 ? s_w[lane] : 0;
+    w = row16_scan_incl(w);
+    const int pre = wave > 0 ? __builtin_amdgcn_readlane(w, wave - 1) : 0;
+    return v + pre;
+}
+
+template <int SEGV>
+__global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
+    const bf16_t* __restrict__ score,      // [B][score_stride] (nullable: then cur_in is used)
+    const int64_t* __restrict__ lm_idx,    // [B][N] slot -> chunk id (nullable: identity)
+    const int64_t* __restrict__ cur_in,    // [B][S] ids selected by the caller (legacy path)
+    int64_t* __restrict__ cached,          // [B][S] in: resident ids per slot; out: reordered ids
+    int32_t* __restrict__ offsets, int32_t* __restrict__ cnts, int64_t* __restrict__ sel_out,
+    int32_t* __restrict__ dst_slots,       // nullable; non-null = in-place layout (see skv_topk_reorder_kernel)
+    int N, int score_stride, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* s_hist = smem;                               // [T2_BINS / 2][T2_COPIES], two 16-bit bins per word
+    int* s_cur = s_hist + (T2_BINS / 2) * T2_COPIES;  // [SP]
+    int* s_hkeys = s_cur + SP;                        // [H]
+    int* s_hvals = s_hkeys + H;                       // [H]
+    int* s_byslot = s_hvals + H;                      // [SP]
+    int* s_miss = s_byslot + SP;                      // [SP]
+    int* s_rank = s_miss + SP;                        // [SP]
+    int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
+    int* s_out = s_w + 80;                            // [16]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // everything whose address is known is requested first: the resident id of this thread's slot, the thread's scores
+    const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
+    u32x4 sv[SEGV];
+    if (score != nullptr) {
+        const u32x4* gvec = reinterpret_cast<const u32x4*>(score + (size_t)b * score_stride);
+        const int nvec = score_stride / 8;
+#pragma unroll
+        for (int k = 0; k < SEGV; ++k) {
+            const int vi = tid * SEGV + k;
+            sv[k] = vi < nvec ? gvec[vi] : (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    {   // LDS init: histogram (16 words per thread), hash set, slot arrays
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+        for (int k = 0; k < (T2_BINS / 2) * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < H; i += T2_THREADS) {
+            s_hkeys[i] = -1;
+            s_hvals[i] = 0x7fffffff;
+        }
+        for (int i = tid; i < SP; i += T2_THREADS) {
+            s_byslot[i] = -1;
+            s_rank[i] = 0;
+        }
+    }
+    auto insert_resident = [&]() __attribute__((always_inline)) {
+        if (tid < S && my_cached >= 0) {
+            unsigned pos = (unsigned)my_cached & (unsigned)(H - 1);
+            for (int probe = 0; probe < H; ++probe) {
+                int prev = atomicCAS(&s_hkeys[pos], -1, my_cached);
+                if (prev == -1 || prev == my_cached) {
+                    atomicMin(&s_hvals[pos], tid);
+                    break;
+                }
+                pos = (pos + 1) & (unsigned)(H - 1);
+            }
+        }
+    };
+    int my_key = -1;   // id selected into position tid (tid < S)
+
+    if (score != nullptr) {
+        const int j0 = tid * SEGV * 8;     // first score index of this thread
+#define key_of(k, e) (((e) & 1) ? (int)(sv[k][(e) >> 1] >> 16) : (int)(sv[k][(e) >> 1] & 0xffffu))
+        int kmx = 0;
+#pragma unroll
+        for (int k = 0; k < SEGV; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (j0 + k * 8 + e < N) kmx = max(kmx, key_of(k, e));
+        kmx = wave_max_i32_dpp(kmx);
+        if (lane == 0) s_w[64 + wave] = kmx;
+        __syncthreads();                                   // (A) LDS initialised, wave maxima visible
+        int base;
+        {
+            int w = lane < 16 ? s_w[64 + lane] : 0;
+            base = wave_max_i32_dpp(w);
+        }
+        const int cpy = lane & (T2_COPIES - 1);
+        int need = S, thr = 0, need_eq = 0;
+        for (int round = 0;; ++round) {
+            // keys in (base - 4095, base] get their own bin (rel = base - key), everything lower shares bin 4095
+#pragma unroll
+            for (int k = 0; k < SEGV; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int val = key_of(k, e);
+                    if (j0 + k * 8 + e < N && val <= base) {
+                        const int rel = min(base - val, T2_BINS - 1);
+                        atomicAdd(&s_hist[(rel >> 1) * T2_COPIES + cpy], 1 << ((rel & 1) * 16));
+                    }
+                }
+            if (round == 0) insert_resident();
+            __syncthreads();                               // (B)
+            // fold the copies: thread t owns words 2t, 2t+1 = bins 4t .. 4t+3 (ascending rel = descending key)
+            int c[4] = {0, 0, 0, 0};
+            {
+                const u32x4* hw = reinterpret_cast<const u32x4*>(s_hist + (size_t)tid * 2 * T2_COPIES);
+#pragma unroll
+                for (int q = 0; q < 2 * T2_COPIES / 4; ++q) {
+                    const u32x4 w4 = hw[q];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int word = (q * 4 + x) / T2_COPIES;       // 0 or 1
+                        c[word * 2] += (int)(w4[x] & 0xffffu);
+                        c[word * 2 + 1] += (int)(w4[x] >> 16);
+                    }
+                }
+            }
+            const int tot = (c[0] + c[1]) + (c[2] + c[3]);
+            const int incl = block_scan_incl1(tot, s_w + 16 * (round & 1), tid);      // barrier (C)
+            int run = incl - tot;
+            if (run < need && incl >= need) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (run < need && run + c[x] >= need) {
+                        s_out[0] = 4 * tid + x;
+                        s_out[1] = run;
+                    }
+                    run += c[x];
+                }
+            }
+            __syncthreads();                               // (D)
+            const int rel_thr = s_out[0], above = s_out[1];
+            if (rel_thr < T2_BINS - 1) {
+                thr = base - rel_thr;
+                need_eq = need - above;
+                break;
+            }
+            // the k-th value lies among the keys <= base - 4095: slide the window (never for softmax scores of one head)
+            need -= above;
+            base -= T2_BINS - 1;
+            u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+            for (int k = 0; k < (T2_BINS / 2) * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+        // ---- ordered compaction: (#greater, #equal capped at the quota) before this thread, one packed scan
+        int cg = 0, ce = 0;
+#pragma unroll
+        for (int k = 0; k < SEGV; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = key_of(k, e);
+                const bool in = j0 + k * 8 + e < N;
+                cg += in && val > thr;
+                ce += in && val == thr;
+            }
+        ce = min(ce, need_eq);      // only "fewer than the quota so far" matters downstream; keeps the packed sum in range
+        const int packed = cg | (ce << 10);
+        const int pincl = block_scan_incl1(packed, s_w + 32, tid);                    // barrier (E)
+        const int pexcl = pincl - packed;
+        int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+#pragma unroll
+        for (int k = 0; k < SEGV; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int val = key_of(k, e);
+                const int j = j0 + k * 8 + e;
+                if (j < N) {
+                    int pos = -1;
+                    if (val > thr) {
+                        pos = gt_run + min(eq_run, need_eq);
+                        ++gt_run;
+                    } else if (val == thr) {
+                        if (eq_run < need_eq) pos = gt_run + eq_run;
+                        ++eq_run;
+                    }
+                    if (pos >= 0) s_cur[pos] = j;
+                }
+            }
+        __syncthreads();                                   // (F)
+#undef key_of
+        if (tid < S) {
+            const int j = s_cur[tid];
+            const long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
+            my_key = (int)id;
+            if (sel_out) sel_out[(size_t)b * S + tid] = id;
+        }
+    } else {
+        if (tid < S) my_key = (int)cur_in[(size_t)b * S + tid];
+        __syncthreads();     // hash arrays initialised
+        insert_resident();
+        __syncthreads();
+    }
+
+    // ---- classify the new ids against the resident set
+    int my_slot = -1;
+    if (tid < S) {
+        if (my_key >= 0) {
+            unsigned pos = (unsigned)my_key & (unsigned)(H - 1);
+            for (int probe = 0; probe < H; ++probe) {
+                int k2 = s_hkeys[pos];
+                if (k2 == my_key) {
+                    my_slot = s_hvals[pos];
+                    break;
+                }
+                if (k2 == -1) break;
+                pos = (pos + 1) & (unsigned)(H - 1);
+            }
+        }
+        if (my_slot >= 0) s_byslot[my_slot] = my_key;
+    }
+    __syncthreads();
+    // hits ordered by old slot (compaction of s_byslot), misses in selection order
+    const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
+    const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
+    const int hm = block_scan_incl1(is_hit_slot | (is_miss << 16), s_w + 48, tid);
+    const int hit_incl = hm & 0xffff, miss_incl = hm >> 16;
+    if (tid == T2_THREADS - 1) {
+        s_out[4] = hit_incl;
+        s_out[5] = miss_incl;
+    }
+    if (is_miss) s_miss[miss_incl - 1] = my_key;
+    int* s_free = s_hvals;  // the hash values are dead after the classification: r-th free slot (ascending)
+    if (dst_slots && tid < S && !is_hit_slot) s_free[tid - hit_incl] = tid;
+    __syncthreads();
+    const int cnt = s_out[4], nm = s_out[5];
+    // misses ordered by chunk id: usually sorted already (ascending landmark slot, increasing slot -> id map)
+    const int unsorted_here = (tid > 0 && tid < nm && s_miss[tid - 1] > s_miss[tid]) ? 1 : 0;
+    if (__syncthreads_or(unsorted_here)) {
+        const int P = T2_THREADS / SP;
+        const int i = tid / P, part = tid % P;
+        if (i < nm) {
+            const int ki = s_miss[i];
+            int r = 0;
+            for (int j = part; j < nm; j += P) {
+                int kj = s_miss[j];
+                r += (kj < ki) || (kj == ki && j < i);
+            }
+            if (r) atomicAdd(&s_rank[i], r);
+        }
+        __syncthreads();
+    } else if (tid < nm) {
+        s_rank[tid] = tid;        // read back by the same thread below
+    }
+    // ---- write out
+    if (dst_slots) {
+        if (tid < nm) {
+            const int key = s_miss[tid], r = s_rank[tid], slot = s_free[r];
+            cached[(size_t)b * S + slot] = (long long)key;
+            offsets[(size_t)b * S + cnt + r] = key;
+            dst_slots[(size_t)b * S + cnt + r] = slot;
+        }
+        if (tid == 0) cnts[b] = cnt;
+        return;
+    }
+    if (is_hit_slot) {
+        int o = hit_incl - 1;
+        cached[(size_t)b * S + o] = (long long)s_byslot[tid];
+        offsets[(size_t)b * S + o] = tid;
+    }
+    if (tid < nm) {
+        int key = s_miss[tid], o = cnt + s_rank[tid];
+        cached[(size_t)b * S + o] = (long long)key;
+        offsets[(size_t)b * S + o] = key;
+    }
+    if (tid == 0) cnts[b] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
 static inline int next_pow2(int v) {
@@ -648,6 +946,23 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
     return SKV_OK;
 }
 
+template <int SEGV>
+static int launch_topk2(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
+                        int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
+                        int SP, hipStream_t st) {
+    const size_t smem = (size_t)((T2_BINS / 2) * T2_COPIES + SP * 4 + H * 2 + 80 + 16) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)skv_topk2_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)((T2_BINS / 2) * T2_COPIES + 1024 * 4 + 4096 * 2 + 96) * sizeof(int))) != hipSuccess)
+            return SKV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
+                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP);
+    return SKV_OK;
+}
+
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st) {
@@ -655,6 +970,16 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
     if (score != nullptr && (N < S || score_stride < N || (score_stride % 8))) return SKV_ERR_ARG;
     const int SP = next_pow2(S);
     const int H = 4 * SP;
+#ifndef SKV_TOPK_V1
+    {   // second-generation kernel: scores in registers, <= 16 vectors (128 scores) per thread
+        const int per_thread = score ? (score_stride / 8 + T2_THREADS - 1) / T2_THREADS : 1;
+        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+    }
+#endif
     const size_t base = (size_t)(SP * 4 + H * 2 + 256 + 32 + 8 + 256 * 32) * sizeof(int);
     const size_t with_score = base + (size_t)score_stride * sizeof(bf16_t);
     const bool stage = score != nullptr && with_score <= 150 * 1024;

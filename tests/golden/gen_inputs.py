@@ -93,3 +93,26 @@ def rope_glm_torch(x, cos_sin, position_ids):
 
 def rope_torch(case, x, cos_sin, position_ids):
     return rope_glm_torch(x, cos_sin, position_ids) if CASES[case]["glm"] else rope_neox_torch(x, cos_sin, position_ids)
+
+
+# ---- selection stage at the headline size (tests/golden/select_122k.npz) ------------------------------------
+SELECT_122K = dict(q_heads=32, kv_heads=8, head_dim=128, L=122 * 1024, budget=2048, chunk=8, rank=160, seed=2468)
+
+
+def make_select_122k_inputs():
+    """Post-RoPE keys with chunk structure (so landmarks carry signal and the scores have a realistic spread), V, and two
+    queries aligned with a few chunks.  Only make_golden.py needs these (the fixture stores the scores themselves)."""
+    c = SELECT_122K
+    g = torch.Generator().manual_seed(c["seed"])
+    L, kv, D, C = c["L"], c["kv_heads"], c["head_dim"], c["chunk"]
+    centers = torch.randn(1, kv, L // C, 1, D, generator=g)
+    k = (centers + 0.7 * torch.randn(1, kv, L // C, C, D, generator=g)).view(1, kv, L, D).to(torch.bfloat16)
+    v = torch.randn(1, kv, L, D, generator=g).to(torch.bfloat16)
+    qs = []
+    for _ in range(2):
+        q = torch.randn(1, c["q_heads"], 1, D, generator=g)
+        pick = torch.randint(0, L // C, (c["q_heads"],), generator=g)
+        for h in range(c["q_heads"]):
+            q[0, h, 0] += 1.5 * centers[0, h // (c["q_heads"] // kv), pick[h], 0]
+        qs.append((q * 1.2).to(torch.bfloat16))
+    return dict(k_roped=k, v=v, q_steps=torch.stack(qs))

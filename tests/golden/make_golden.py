@@ -29,6 +29,7 @@ import importlib.util
 import os
 import sys
 import types
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -167,8 +168,44 @@ def shrink(case, out):
     return res
 
 
+def run_select_122k(ref):
+    """Top-k stage at the headline size (BASELINE config 1: L = 124,928, budget 2,048 -> N = 15,560 landmarks, S = 256):
+    the reference's pure-torch ShadowKVCache is prefilled on seeded synthetic K / V (inputs from gen_inputs, not stored)
+    and its own get_retrieval_position_ids (models/kv_cache.py:421-445) runs for two queries.  Stored: the bf16 scores
+    its torch.topk ran on (recomputed with the same ops, :425-433), the chunk ids it selected, and k_landmark_idx -
+    i.e. inputs and outputs of the selection stage alone (torch.topk + gather, the stage kv_cache.py:1031-1042 repeats
+    on the CUDA path)."""
+    import math
+    c = G.SELECT_122K
+    cfg = SimpleNamespace(num_hidden_layers=1, num_attention_heads=c["q_heads"], num_key_value_heads=c["kv_heads"],
+                          hidden_size=c["q_heads"] * c["head_dim"])
+    inp = G.make_select_122k_inputs()
+    cache = ref.ShadowKVCache(cfg, batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    cache.prefill_kv_cache(inp["v"], 0, inp["k_roped"], inp["q_steps"][0])
+    kv, Gq = c["kv_heads"], c["q_heads"] // c["kv_heads"]
+    attns, sels = [], []
+    for t in range(inp["q_steps"].shape[0]):
+        q = inp["q_steps"][t]
+        ca = torch.einsum('bhgqd,bhdc->bhgqc', q.view(-1, kv, Gq, 1, 128),
+                          cache.k_landmark[0].transpose(2, 3)).squeeze(2) / math.sqrt(128)
+        ca = torch.nn.functional.softmax(ca, dim=-1, dtype=torch.float32).to(torch.bfloat16).sum(dim=-2)
+        ca, _ = torch.max(ca, dim=-2)
+        attns.append(u16(ca))
+        cache.get_retrieval_position_ids(0, q)
+        sels.append(cache.selected_chunk_idx[0].numpy().copy())
+    lm_idx = cache.k_landmark_idx[0].numpy()
+    return {"chunk_attn": np.stack(attns), "sel": np.stack(sels), "lm_idx": lm_idx.astype(np.int32),
+            "meta": np.array([cache.chunks, cache.select_sets, cache.outlier_chunk, lm_idx.shape[-1]], dtype=np.int64)}
+
+
 def main():
     ref = load_reference_kv_cache()
+    if "--only-small" not in sys.argv:
+        out = run_select_122k(ref)
+        path = os.path.join(HERE, "select_122k.npz")
+        np.savez_compressed(path, **out)
+        print("select_122k", {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
     for case in G.CASES:
         out = shrink(case, run_case(ref, case))
         path = os.path.join(HERE, f"{case}.npz")

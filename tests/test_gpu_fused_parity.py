@@ -6,7 +6,11 @@ import pytest
 import torch
 
 import oracle
-from util import ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step
+import os
+
+import numpy as np
+
+from util import ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step, check_topk_against_reference
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -126,6 +130,99 @@ def test_select_chunks_inplace(blocks, G, N, S, overlap):
         assert torch.all(mids[b, :k] == -7) and torch.all(slots[b, :k] == -7)     # nothing written for hits
 
 
+def _select_from_scores(score, lm_idx, cached, S, inplace=False):
+    """skv_select_from_scores on the device: (selected ids, cached after, offsets, cnts, dst_slots)."""
+    L = _lib()
+    blocks, N = score.shape
+    stride = (N + 7) // 8 * 8
+    sc = torch.full((blocks, stride), 0x7f7f, dtype=torch.int16).view(torch.bfloat16)   # padding: large garbage, must be ignored
+    sc[:, :N] = score
+    scd = sc.to(DEV)
+    c = cached.to(DEV); off = torch.full((blocks, S), -7, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(blocks, dtype=torch.int32, device=DEV); sel = torch.zeros(blocks, S, dtype=torch.int64, device=DEV)
+    dst = torch.full((blocks, S), -7, dtype=torch.int32, device=DEV) if inplace else None
+    lid = lm_idx.to(DEV) if lm_idx is not None else None
+    L.check(L.lib().skv_select_from_scores(scd.data_ptr(), stride, L.ptr(lid), c.data_ptr(), off.data_ptr(), L.ptr(dst),
+                                           cnt.data_ptr(), sel.data_ptr(), blocks, N, S, _stream()), "select_from_scores")
+    torch.cuda.synchronize()
+    return sel.cpu(), c.cpu(), off.cpu(), cnt.cpu(), (dst.cpu() if inplace else None)
+
+
+def _oracle_from_scores(score, lm_idx, cached, S):
+    blocks, N = score.shape
+    sel = oracle.group_max_topk(score.view(blocks, 1, N).contiguous(), lm_idx, blocks, 1, N, S)
+    c = cached.clone(); off = torch.zeros(blocks, S, dtype=torch.int32); cnt = torch.zeros(blocks, dtype=torch.int32)
+    oracle.reorder_keys_and_compute_offsets(c, sel, off, cnt, 1, blocks, S)
+    return sel, c, off, cnt
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("case", ["llama_small", "llama_cpu_b1024", "glm_small", "select_122k"])
+def test_topk_stage_pinned_to_reference_scores(case):
+    """The device's selection stage alone (skv_select_from_scores = the top-k / diff kernel of the decode path) on the
+    bf16 scores the REFERENCE's torch.topk ran on (fixtures made by tests/golden/make_golden.py from the imported
+    reference, models/kv_cache.py:421-445): same set as the reference modulo slots tied at the k-th value, identical
+    where the boundary is unique; and identical to the oracle, reordering included.  select_122k = headline size."""
+    z = np.load(os.path.join(GOLD, f"{case}.npz"))
+    lm_idx = torch.from_numpy(z["lm_idx"][0].astype(np.int64)).contiguous()
+    kv, N = lm_idx.shape
+    g = torch.Generator().manual_seed(5)
+    for t in range(z["sel"].shape[0]):
+        score = torch.from_numpy(z["chunk_attn"][t][0].astype(np.int16)).view(torch.bfloat16).contiguous()
+        ref_ids = torch.from_numpy(z["sel"][t][0])
+        S = ref_ids.shape[-1]
+        # resident set: the reference's previous selection (step 0: a random one) -> realistic hit / miss mix
+        cached = (torch.from_numpy(z["sel"][t - 1][0]).clone() if t > 0
+                  else torch.stack([lm_idx[h][torch.randperm(N, generator=g)[:S]] for h in range(kv)]))
+        sel, c, off, cnt, _ = _select_from_scores(score, lm_idx, cached, S)
+        check_topk_against_reference(score, lm_idx, ref_ids, sel, f"{case} step {t}")
+        o = _oracle_from_scores(score, lm_idx, cached, S)
+        assert torch.equal(sel, o[0]) and torch.equal(c, o[1]) and torch.equal(off, o[2]) and torch.equal(cnt, o[3])
+        # in-place layout: same set
+        sel2, c2, _, cnt2, _ = _select_from_scores(score, lm_idx, cached, S, inplace=True)
+        assert torch.equal(sel2, sel) and torch.equal(cnt2, cnt)
+        assert [sorted(r) for r in c2.tolist()] == [sorted(r) for r in c.tolist()]
+
+
+@pytest.mark.parametrize("blocks,N,S,kind", [
+    (3, 5000, 256, "wide"),        # k-th value > 32 binades below the maximum: the histogram window must slide
+    (2, 9000, 256, "wide2"),       # two slides
+    (2, 4096, 256, "flat"),        # every score equal: the whole row ties at the k-th value
+    (2, 777, 777, "all"),          # S == N, N not a multiple of 8
+    (2, 15560, 256, "steps"),      # few distinct values, k-th value tied thousands of times
+    (1, 40000, 512, "seg8"),       # 8 vectors per thread
+    (1, 131056, 256, "seg16"),     # 16 vectors per thread (1M-token context)
+    (2, 300, 32, "zeros"),         # fewer non-zero scores than S: zeros tie at the k-th value
+])
+def test_select_from_scores_edge_cases(blocks, N, S, kind):
+    g = torch.Generator().manual_seed(N + S)
+    if kind in ("wide", "wide2"):
+        # 100 scores near 1, the rest spread over 1e-12 .. 1e-30 (wide2: 1e-25 .. 1e-36): the 256th value is far below
+        lo, hi = (-30.0, -12.0) if kind == "wide" else (-36.0, -25.0)
+        x = 10.0 ** (torch.rand(blocks, N, generator=g) * (hi - lo) + lo)
+        top = torch.stack([torch.randperm(N, generator=g)[:100] for _ in range(blocks)])
+        x.scatter_(1, top, torch.rand(blocks, 100, generator=g) * 0.5 + 0.5)
+    elif kind == "flat":
+        x = torch.full((blocks, N), 1.0 / N)
+    elif kind == "steps":
+        x = torch.tensor([1e-3, 3e-4, 1e-4, 6e-5])[torch.randint(0, 4, (blocks, N), generator=g)]
+        x[:, ::97] = 0.02
+    elif kind == "zeros":
+        x = torch.zeros(blocks, N)
+        x[:, ::29] = torch.rand(blocks, len(range(0, N, 29)), generator=g)
+    else:
+        x = torch.softmax(torch.randn(blocks, N, generator=g) * 3, dim=-1)
+    score = x.bfloat16()
+    lm_idx = torch.stack([torch.sort(torch.randperm(N + 48, generator=g)[:N]).values for _ in range(blocks)]).to(torch.int64)
+    cached = torch.stack([lm_idx[b][torch.randperm(N, generator=g)[:S]] for b in range(blocks)])
+    o = _oracle_from_scores(score, lm_idx, cached, S)
+    r = _select_from_scores(score, lm_idx, cached, S)
+    assert torch.equal(r[0], o[0]), "selected ids"
+    assert torch.equal(r[1], o[1]) and torch.equal(r[2], o[2]) and torch.equal(r[3], o[3])
+
+
 def test_select_chunks_ties():
     """Massive ties at the threshold: duplicated landmarks give identical bf16 scores; the contract
     (lowest landmark slot wins) must hold bit-exactly."""
@@ -214,10 +311,19 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
     for kvp, host_len in ((0, kv_len), (kv_dev.data_ptr(), 0)):
         out.zero_()
         rc = L.lib().skv_sparse_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                          kvp, host_len, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream())
+                                          kvp, host_len, rows, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream())
         L.check(rc, "skv_sparse_attention")
         torch.cuda.synchronize()
         o1 = out.cpu().float()
         # tolerance: fp16-level 1e-3 relative (north_star) + half a bf16 ulp of the output rounding
         tol = 1e-3 * o0f.abs() + 2.0 ** -8 * o0f.abs() + 1e-5
         assert bool(((o1 - o0f).abs() <= tol).all()), f"max abs err {float((o1 - o0f).abs().max())}"
+    # kv_len past the rows a head owns: refused from the host, clamped from the device (never reads the next head)
+    a = (qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), ws.data_ptr())
+    assert L.lib().skv_sparse_attention(*a, 0, rows + 1, rows, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream()) == -1
+    kv_dev.fill_(rows + 1000)
+    L.check(L.lib().skv_sparse_attention(*a, kv_dev.data_ptr(), 0, rows, rows * 128, bs, Hq, Hkv, 128, splits, scale,
+                                         _stream()), "skv_sparse_attention")
+    torch.cuda.synchronize()
+    _, full = oracle.sparse_attention(q, k, v, rows, scale)
+    assert bool(((out.cpu().float() - full).abs() <= 1e-3 * full.abs() + 2.0 ** -8 * full.abs() + 1e-5).all())

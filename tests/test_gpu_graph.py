@@ -381,3 +381,75 @@ def test_sample_advance_kernel_distribution_and_counters():
     # top_p = 0 disables the nucleus filter: the tail (p ~ 1e-14) is still never drawn, the four tokens are
     draws = run(vals.contiguous(), 0.0, 200)
     assert (draws[:, 1] - 1050).max() <= 3
+
+
+@torch.inference_mode()
+def test_captured_batch2_full_vocabulary_replays_like_eager():
+    """The mode that faulted in round 1: a CAPTURED decode step with bs = 2 over the real vocabulary (128,256 logits per
+    sequence, sampling at temperature 0.6 with the two-level top-k) replayed several times.  Tokens, chunk bookkeeping
+    and cache bytes must equal the eager run of the same step function from the same state (the sampler is counter-based:
+    same seed and positions -> same draws)."""
+    from shadowkv_amd import llama
+    cfg = llama.ModelConfig(name="wide-vocab", hidden_size=4096, intermediate_size=2048, num_hidden_layers=2,
+                            num_attention_heads=32, num_key_value_heads=8, vocab_size=128256)
+
+    def make():
+        m = llama.DecoderLM(cfg=cfg, batch_size=2, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
+                            seed=5, chunk_layout="inplace", overlap_attention=True)
+        llama.build_synthetic_context(m, 4608, seed=77)
+        return m
+    steps, tok0 = 7, torch.tensor([[17], [4242]], device=DEV)
+    m1 = make()
+    d1 = llama.GraphDecoder(m1, temperature=0.6, seed=99)           # never captured: every step eager
+    d1.token.copy_(tok0)
+    t1 = [d1.step().flatten().tolist() for _ in range(steps)]
+    torch.cuda.synchronize()
+    m2 = make()
+    d2 = llama.GraphDecoder(m2, temperature=0.6, seed=99)
+    d2.token.copy_(tok0)
+    warm = d2.capture(warmup=2)
+    t2 = [d2.step().flatten().tolist() for _ in range(steps - warm)]
+    torch.cuda.synchronize()
+    assert d2.graph is not None
+    assert t2 == t1[warm:], (t1, t2)
+    c1, c2 = m1.kv_cache, m2.kv_cache
+    assert c1.kv_offset == c2.kv_offset and c1.gen_offset == c2.gen_offset == steps
+    assert torch.equal(c1.position_ids, c2.position_ids)
+    assert torch.equal(c1.k_cache_buffer.view(torch.int16), c2.k_cache_buffer.view(torch.int16))
+    assert torch.equal(c1.v_cache_buffer.view(torch.int16), c2.v_cache_buffer.view(torch.int16))
+    assert torch.equal(d1.pos, d2.pos) and torch.equal(d1.kv_len, d2.kv_len) and torch.equal(d1.gen, d2.gen)
+
+
+@torch.inference_mode()
+def test_decode_refuses_to_run_past_the_generated_row_slack():
+    """budget 256 -> 128 generated rows behind the sparse region.  Eager fused decode up to the last row matches the
+    reference call order's bookkeeping, the step after it raises (the reference silently drops the token,
+    kv_cache.py:1255-1265; attention past the buffer would read the next head's rows); GraphDecoder likewise, unless it
+    is told to treat the rows as a ring (benchmarks), where kv_len stays at the buffer size."""
+    m, llama = _make(layout="inplace", overlap=True)
+    c = m.kv_cache
+    slack = c.k_cache_buffer.shape[-2] - c.sparse_end
+    assert slack == 128 and c.generated_row_slack() == 128
+    t = torch.tensor([[3]], device=DEV)
+    for _ in range(slack):
+        t = m.decode_step(t, temperature=0.0)
+    torch.cuda.synchronize()
+    assert c.gen_offset == slack and c.generated_row_slack() == 0
+    with pytest.raises(RuntimeError):
+        m.decode_step(t, temperature=0.0)
+    assert c.gen_offset == slack                                   # nothing was appended by the refused step
+    m2, _ = _make(layout="inplace", overlap=True)
+    d = llama.GraphDecoder(m2, temperature=0.0)
+    d.capture(warmup=2)
+    for _ in range(slack - 2):
+        d.step()
+    with pytest.raises(RuntimeError):
+        d.step()
+    m3, _ = _make(layout="inplace", overlap=True)
+    d3 = llama.GraphDecoder(m3, temperature=0.0, ring_slack=True)
+    d3.capture(warmup=2)
+    for _ in range(slack + 5):
+        d3.step()
+    torch.cuda.synchronize()
+    rows = m3.kv_cache.k_cache_buffer.shape[-2]
+    assert int(d3.kv_len) == rows and int(d3.row_idx) == m3.kv_cache.sparse_end + (slack + 7) % slack

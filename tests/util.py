@@ -38,3 +38,53 @@ def make_selection_step(gen, n_chunks, S, hit_frac, cached=None):
     new = rest[torch.randperm(rest.numel(), generator=gen)[: S - n_hit]]
     cur = torch.cat([keep, new])[torch.randperm(S, generator=gen)]
     return cached.to(torch.int64), cur.to(torch.int64)
+
+
+def check_topk_against_reference(score, lm_idx, ref_ids, got_ids, what=""):
+    """Selection-stage pin against the reference's own torch.topk (fixtures: the bf16 scores it ran on and the chunk
+    ids it returned, models/kv_cache.py:421-445 / :1031-1042).  Membership under exact bf16 ties at the k-th value is
+    not defined by the reference (torch.topk's tie order is undocumented), so per head:
+      * every slot scoring strictly above the k-th value is in both sets;
+      * everything else either set holds scores exactly the k-th value;
+      * where the k-th value is not tied across the boundary, the sets are equal;
+      * this build's contract on top: among the ties, the lowest landmark slots win.
+    score bf16 [H, N]; lm_idx int [H, N]; ref_ids / got_ids int [H, S] chunk ids.  Returns the number of heads whose
+    boundary was tied (the reference's choice was then one of several valid ones)."""
+    H, N = score.shape
+    S = ref_ids.shape[-1]
+    key = bits(score)                                      # scores are >= 0: the bf16 pattern orders like the value
+    tied_heads = 0
+    for h in range(H):
+        slot_of = {int(c): j for j, c in enumerate(lm_idx[h].tolist())}
+        ref = {slot_of[int(c)] for c in ref_ids[h].tolist()}
+        got = {slot_of[int(c)] for c in got_ids[h].tolist()}
+        assert len(ref) == S and len(got) == S, f"{what} head {h}: duplicate ids"
+        k = key[h]
+        thr = int(torch.sort(k, descending=True).values[S - 1])
+        above = set((k > thr).nonzero().flatten().tolist())
+        ties = (k == thr).nonzero().flatten().tolist()
+        need = S - len(above)
+        assert above <= ref and above <= got, f"{what} head {h}: a slot above the k-th value is missing"
+        assert all(int(k[j]) == thr for j in ref - above) and all(int(k[j]) == thr for j in got - above), \
+            f"{what} head {h}: a selected slot scores below the k-th value"
+        assert got - above == set(ties[:need]), f"{what} head {h}: ties at the k-th value must go to the lowest slots"
+        if len(ties) == need:
+            assert got == ref, f"{what} head {h}: unique boundary, sets must be identical"
+        else:
+            tied_heads += 1
+    return tied_heads
+
+
+def rope_pair_bound(pre, glm):
+    """Per-element bound on |K_device - K_oracle| for rebuilt rows: the MFMA sums the 160 products in its own order, so
+    a small fraction of the pre-RoPE bf16 roundings flip by one ulp (2^-8 relative); a flipped x1 or x2 moves both
+    outputs of its rotation pair by at most 2^-8 (|x1| + |x2|) plus their own roundings -> 2^-6 (|x1| + |x2|).
+    pre: the oracle's pre-RoPE bf16 rows [..., 128]."""
+    x = pre.float().abs()
+    if glm:
+        pair = x[..., 0:64:2] + x[..., 1:64:2]
+        mag = torch.cat((torch.stack((pair, pair), -1).flatten(-2), x[..., 64:]), -1)
+    else:
+        pair = x[..., :64] + x[..., 64:]
+        mag = torch.cat((pair, pair), -1)
+    return 2.0 ** -6 * mag + 1e-6
