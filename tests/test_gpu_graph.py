@@ -422,14 +422,14 @@ def test_captured_batch2_full_vocabulary_replays_like_eager():
 
 @torch.inference_mode()
 def test_decode_refuses_to_run_past_the_generated_row_slack():
-    """budget 256 -> 128 generated rows behind the sparse region.  Eager fused decode up to the last row matches the
+    """A few dozen generated rows sit behind the sparse region (buf_len - sparse_end: 96 here and at 122K).  Eager fused decode up to the last row matches the
     reference call order's bookkeeping, the step after it raises (the reference silently drops the token,
     kv_cache.py:1255-1265; attention past the buffer would read the next head's rows); GraphDecoder likewise, unless it
     is told to treat the rows as a ring (benchmarks), where kv_len stays at the buffer size."""
     m, llama = _make(layout="inplace", overlap=True)
     c = m.kv_cache
     slack = c.k_cache_buffer.shape[-2] - c.sparse_end
-    assert slack == 128 and c.generated_row_slack() == 128
+    assert 0 < slack <= 128 and c.generated_row_slack() == slack
     t = torch.tensor([[3]], device=DEV)
     for _ in range(slack):
         t = m.decode_step(t, temperature=0.0)

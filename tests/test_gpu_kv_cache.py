@@ -349,10 +349,12 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     got = out.view(1, Hq, D).cpu().float()
     tol = 1e-3 * a32.abs() + 2.0 ** -8 * a32.abs() + 1e-5
     assert bool(((got - a32).abs() <= tol).all()), f"attention exceeds the bound by {float(((got - a32).abs() - tol).max())}"
-    # kv_len from device memory gives the same bits; a host kv_len past the buffer is refused
+    # kv_len from device memory (the state is now all hits: same rows, another split of the f32 sums); a host kv_len
+    # past the buffer is refused
     kvd = torch.tensor([kv_len], dtype=torch.int32, device=DEV)
     out2 = cache.select_fetch_attend_inplace(0, q, cs, kv_len=0, kv_len_dev=kvd)
     torch.cuda.synchronize()
-    assert_bits_equal(out, out2, "kv_len on the device")
+    assert cache.cnts.cpu().tolist() == [S] * kv_heads
+    assert bool(((out2.view(1, Hq, D).cpu().float() - a32).abs() <= tol).all()), "kv_len on the device"
     with pytest.raises(ValueError):
         cache.select_fetch_attend_inplace(0, q, cs, kv_len=2593)
