@@ -591,19 +591,40 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 
 // ---------------------------------------------------------------------------------------
 // K2b, second generation (default for N <= 131,072 scores per head): same results as the kernel above with a
-// shorter dependency chain (the kernel is latency-bound: 15 K scores over 1,024 threads are 15 per thread).
-//   * the thread's scores stay in registers (SEGV contiguous 16-B vectors per thread, loaded once);
+// shorter dependency chain and far fewer instructions per score.  One 1,024-thread workgroup per head runs on ONE
+// CU: every instruction a thread executes is issued 16 times on 4 SIMDs (about 20 cycles), so the kernel is bound by
+// instructions per thread (in-kernel stamps, tools/topk_probe.hip: histogram 1.45 us, count 1.2 us, ordered
+// compaction 1.95 us of 9.8 us before this rewrite), not by the 31 KB it reads.
+//   * the thread's scores stay in registers (SEGV contiguous 16-B vectors per thread, loaded once), two 16-bit keys
+//     per word, and are processed two at a time with packed 16-bit arithmetic;
 //   * ONE histogram pass finds the exact k-th value: 4,096 bins of the 16-bit pattern counted down from the head's
-//     maximum (32 binades; softmax scores of one head fit - otherwise the window slides and the pass repeats), two
-//     bins per word as 16-bit halves, 8 lane-private copies laid out [word][copy] so the copies of a bin sit in 8
-//     different banks.  Real rows spread over hundreds of these bins, so the serialisation that forced a 32-way
-//     privatised 256-bin histogram + a second pass above does not arise;
+//     maximum (32 binades; softmax scores of one head fit - otherwise the window slides and the pass repeats), 4
+//     lane-private copies per bin laid out [bin][copy].  Real rows spread over hundreds of these bins, so the
+//     serialisation that forced a 32-way privatised 256-bin histogram + a second pass above does not arise;
+//   * "greater" / "greater or equal" flags of the thread's scores are bit masks (one add + three bit operations per
+//     word and mask); counts are popcounts, and the ordered compaction loops over the SET bits only (256 of 15 K
+//     scores are selected);
+//   * the slot -> chunk-id loads of a thread's first two candidates are issued as soon as the k-th value is known
+//     and travel with the candidate, so the (HBM-cold) gather overlaps the block scan;
 //   * block scans keep one barrier (every wave re-scans the 16 wave totals itself), both counters of a scan are
 //     packed into one integer.
+// Padding (scores past N in the last thread's vectors) is rewritten to key 0 at load and its count is subtracted
+// from the bin of key 0; padding has the highest indices, so the tie rule never reaches it.
 // ---------------------------------------------------------------------------------------
 #define T2_THREADS 1024
 #define T2_BINS 4096
-#define T2_COPIES 8
+#define T2_COPIES 4
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
 
 __device__ __forceinline__ int wave_max_i32_dpp(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
@@ -638,9 +659,10 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int32_t* __restrict__ dst_slots,       // nullable; non-null = in-place layout (see skv_topk_reorder_kernel)
     int N, int score_stride, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    int* s_hist = smem;                               // [T2_BINS / 2][T2_COPIES], two 16-bit bins per word
-    int* s_cur = s_hist + (T2_BINS / 2) * T2_COPIES;  // [SP]
-    int* s_hkeys = s_cur + SP;                        // [H]
+    int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
+    int* s_cur = s_hist + T2_BINS * T2_COPIES;        // [SP]   selected landmark slot per output position
+    long long* s_id = reinterpret_cast<long long*>(s_cur + SP);   // [SP] its chunk id (-1: not gathered yet)
+    int* s_hkeys = reinterpret_cast<int*>(s_id + SP);  // [H]
     int* s_hvals = s_hkeys + H;                       // [H]
     int* s_byslot = s_hvals + H;                      // [SP]
     int* s_miss = s_byslot + SP;                      // [SP]
@@ -648,22 +670,28 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TOPK_STAMP(0);
+    constexpr int NW = 4 * SEGV;                      // 32-bit words (two keys each) per thread
+    constexpr int NG = (NW + 15) / 16;                // mask registers: 16 words (32 keys) each
     // everything whose address is known is requested first: the resident id of this thread's slot, the thread's scores
     const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
-    u32x4 sv[SEGV];
+    uint32_t w[NW];
+    const int j0 = tid * SEGV * 8;                    // first score index of this thread
     if (score != nullptr) {
         const u32x4* gvec = reinterpret_cast<const u32x4*>(score + (size_t)b * score_stride);
         const int nvec = score_stride / 8;
 #pragma unroll
         for (int k = 0; k < SEGV; ++k) {
             const int vi = tid * SEGV + k;
-            sv[k] = vi < nvec ? gvec[vi] : (u32x4){0u, 0u, 0u, 0u};
+            const u32x4 v = vi < nvec ? gvec[vi] : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) w[4 * k + x] = v[x];
         }
     }
     {   // LDS init: histogram (16 words per thread), hash set, slot arrays
         u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
 #pragma unroll
-        for (int k = 0; k < (T2_BINS / 2) * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+        for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
         for (int i = tid; i < H; i += T2_THREADS) {
             s_hkeys[i] = -1;
             s_hvals[i] = 0x7fffffff;
@@ -689,51 +717,64 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int my_key = -1;   // id selected into position tid (tid < S)
 
     if (score != nullptr) {
-        const int j0 = tid * SEGV * 8;     // first score index of this thread
-#define key_of(k, e) (((e) & 1) ? (int)(sv[k][(e) >> 1] >> 16) : (int)(sv[k][(e) >> 1] & 0xffffu))
-        int kmx = 0;
+        if (j0 + SEGV * 8 > N) {   // the thread(s) at the end of the row: padding -> key 0
 #pragma unroll
-        for (int k = 0; k < SEGV; ++k)
+            for (int i = 0; i < NW; ++i) {
+                const int j = j0 + 2 * i;
+                w[i] = (j < N ? w[i] & 0xffffu : 0u) | (j + 1 < N ? w[i] & 0xffff0000u : 0u);
+            }
+        }
+        const int n_pad = T2_THREADS * SEGV * 8 - N;   // keys rewritten to 0 (they are histogrammed like any key)
+        uint32_t m2 = w[0];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (j0 + k * 8 + e < N) kmx = max(kmx, key_of(k, e));
-        kmx = wave_max_i32_dpp(kmx);
+        for (int i = 1; i < NW; ++i) m2 = pk_max_u16(m2, w[i]);
+        int kmx = wave_max_i32_dpp((int)max(m2 & 0xffffu, m2 >> 16));
         if (lane == 0) s_w[64 + wave] = kmx;
         __syncthreads();                                   // (A) LDS initialised, wave maxima visible
+        TOPK_STAMP(1);
         int base;
         {
-            int w = lane < 16 ? s_w[64 + lane] : 0;
-            base = wave_max_i32_dpp(w);
+            int wm = lane < 16 ? s_w[64 + lane] : 0;
+            base = wave_max_i32_dpp(wm);
         }
-        const int cpy = lane & (T2_COPIES - 1);
+        char* const hb = reinterpret_cast<char*>(s_hist) + (lane & (T2_COPIES - 1)) * 4;   // this lane's copy
         int need = S, thr = 0, need_eq = 0;
         for (int round = 0;; ++round) {
             // keys in (base - 4095, base] get their own bin (rel = base - key), everything lower shares bin 4095
+            if (round == 0) {      // base is the maximum: every key is <= base
+                const uint32_t base2 = (uint32_t)base * 0x10001u, cap2 = (uint32_t)(T2_BINS - 1) * 0x10001u;
 #pragma unroll
-            for (int k = 0; k < SEGV; ++k)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int val = key_of(k, e);
-                    if (j0 + k * 8 + e < N && val <= base) {
-                        const int rel = min(base - val, T2_BINS - 1);
-                        atomicAdd(&s_hist[(rel >> 1) * T2_COPIES + cpy], 1 << ((rel & 1) * 16));
-                    }
+                for (int i = 0; i < NW; ++i) {
+                    const uint32_t r2 = pk_min_u16(pk_sub_u16(base2, w[i]), cap2);
+                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 & 0xffffu) << 4)), 1);
+                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 >> 16) << 4)), 1);
                 }
-            if (round == 0) insert_resident();
-            __syncthreads();                               // (B)
-            // fold the copies: thread t owns words 2t, 2t+1 = bins 4t .. 4t+3 (ascending rel = descending key)
-            int c[4] = {0, 0, 0, 0};
-            {
-                const u32x4* hw = reinterpret_cast<const u32x4*>(s_hist + (size_t)tid * 2 * T2_COPIES);
+                insert_resident();
+            } else {
 #pragma unroll
-                for (int q = 0; q < 2 * T2_COPIES / 4; ++q) {
-                    const u32x4 w4 = hw[q];
+                for (int i = 0; i < NW; ++i)
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const int word = (q * 4 + x) / T2_COPIES;       // 0 or 1
-                        c[word * 2] += (int)(w4[x] & 0xffffu);
-                        c[word * 2 + 1] += (int)(w4[x] >> 16);
+                    for (int h = 0; h < 2; ++h) {
+                        const int val = h ? (int)(w[i] >> 16) : (int)(w[i] & 0xffffu);
+                        if (val <= base) atomicAdd(reinterpret_cast<int*>(hb + (min(base - val, T2_BINS - 1) << 4)), 1);
                     }
+            }
+            __syncthreads();                               // (B)
+            TOPK_STAMP(2);
+            // fold the copies: thread t owns bins 4t .. 4t+3 (ascending rel = descending key)
+            int c[4];
+            {
+                const u32x4* hw = reinterpret_cast<const u32x4*>(s_hist + (size_t)tid * 4 * T2_COPIES);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const u32x4 w4 = hw[x];
+                    c[x] = (int)((w4[0] + w4[1]) + (w4[2] + w4[3]));
+                }
+                const int relz = min(base, T2_BINS - 1);   // where the padding zeros were counted
+                if ((relz >> 2) == tid) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if ((relz & 3) == x) c[x] -= n_pad;
                 }
             }
             const int tot = (c[0] + c[1]) + (c[2] + c[3]);
@@ -750,6 +791,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
                 }
             }
             __syncthreads();                               // (D)
+            TOPK_STAMP(3);
             const int rel_thr = s_out[0], above = s_out[1];
             if (rel_thr < T2_BINS - 1) {
                 thr = base - rel_thr;
@@ -761,48 +803,90 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
             base -= T2_BINS - 1;
             u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
 #pragma unroll
-            for (int k = 0; k < (T2_BINS / 2) * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+            for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
             __syncthreads();
         }
-        // ---- ordered compaction: (#greater, #equal capped at the quota) before this thread, one packed scan
+        // ---- flags of the thread's keys as bit masks: bit 2i + h of word-group g <=> key (i, h) >= thr (mge) / > thr (mgt).
+        // keys are < 0x8000, so key + (0x8000 - thr) has bit 15 set iff key >= thr, and the two halves of a word never carry
+        // into each other
+        uint32_t mge[NG], mgt[NG];
+        {
+            const uint32_t kge = (0x8000u - (uint32_t)thr) * 0x10001u, kgt = kge - 0x10001u;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                mge[g] = 0u;
+                mgt[g] = 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t te = w[i] + kge, tg = w[i] + kgt;
+                const uint32_t fe = ((te >> 15) & 1u) | ((te >> 31) << 1), fg = ((tg >> 15) & 1u) | ((tg >> 31) << 1);
+                mge[i / 16] |= fe << (2 * (i % 16));
+                mgt[i / 16] |= fg << (2 * (i % 16));
+            }
+        }
         int cg = 0, ce = 0;
 #pragma unroll
-        for (int k = 0; k < SEGV; ++k)
+        for (int g = 0; g < NG; ++g) {
+            cg += __builtin_popcount(mgt[g]);
+            ce += __builtin_popcount(mge[g]);
+        }
+        ce -= cg;
+        // slot -> chunk id of the thread's first two candidates: requested now, consumed after the scan
+        long long id0 = -1, id1 = -1;
+        if (lm_idx != nullptr && cg + ce > 0) {
+            int ord = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int val = key_of(k, e);
-                const bool in = j0 + k * 8 + e < N;
-                cg += in && val > thr;
-                ce += in && val == thr;
+            for (int g = 0; g < NG; ++g) {
+                uint32_t m = mge[g];
+                if (ord < 2 && m) {
+                    const int e0 = __builtin_ctz(m);
+                    m &= m - 1;
+                    if (ord == 0) id0 = lm_idx[(size_t)b * N + j0 + g * 32 + e0];
+                    else id1 = lm_idx[(size_t)b * N + j0 + g * 32 + e0];
+                    ++ord;
+                    if (ord < 2 && m) {
+                        id1 = lm_idx[(size_t)b * N + j0 + g * 32 + __builtin_ctz(m)];
+                        ++ord;
+                    }
+                }
             }
+        }
+        // ---- ordered compaction: (#greater, #equal capped at the quota) before this thread, one packed scan
         ce = min(ce, need_eq);      // only "fewer than the quota so far" matters downstream; keeps the packed sum in range
         const int packed = cg | (ce << 10);
         const int pincl = block_scan_incl1(packed, s_w + 32, tid);                    // barrier (E)
         const int pexcl = pincl - packed;
-        int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+        TOPK_STAMP(4);
+        {
+            int gt_run = pexcl & 1023, eq_run = pexcl >> 10, ord = 0;
 #pragma unroll
-        for (int k = 0; k < SEGV; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int val = key_of(k, e);
-                const int j = j0 + k * 8 + e;
-                if (j < N) {
+            for (int g = 0; g < NG; ++g) {
+                uint32_t m = mge[g];
+                while (m) {
+                    const int e = __builtin_ctz(m);
+                    m &= m - 1;
                     int pos = -1;
-                    if (val > thr) {
+                    if ((mgt[g] >> e) & 1u) {
                         pos = gt_run + min(eq_run, need_eq);
                         ++gt_run;
-                    } else if (val == thr) {
+                    } else {
                         if (eq_run < need_eq) pos = gt_run + eq_run;
                         ++eq_run;
                     }
-                    if (pos >= 0) s_cur[pos] = j;
+                    if (pos >= 0) {
+                        s_cur[pos] = j0 + g * 32 + e;
+                        s_id[pos] = lm_idx == nullptr ? (long long)(j0 + g * 32 + e) : ord == 0 ? id0 : ord == 1 ? id1 : -1ll;
+                    }
+                    ++ord;
                 }
             }
+        }
         __syncthreads();                                   // (F)
-#undef key_of
+        TOPK_STAMP(5);
         if (tid < S) {
-            const int j = s_cur[tid];
-            const long long id = lm_idx ? lm_idx[(size_t)b * N + j] : (long long)j;
+            long long id = s_id[tid];
+            if (id < 0) id = lm_idx[(size_t)b * N + s_cur[tid]];     // third and later candidates of one thread (rare)
             my_key = (int)id;
             if (sel_out) sel_out[(size_t)b * S + tid] = id;
         }
@@ -814,6 +898,10 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     }
 
     // ---- classify the new ids against the resident set
+#ifdef SKV_TOPK_STAMPS
+    if (my_key == -12345) s_out[9] = 1;   // waits for the id gather
+    TOPK_STAMP(6);
+#endif
     int my_slot = -1;
     if (tid < S) {
         if (my_key >= 0) {
@@ -831,6 +919,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         if (my_slot >= 0) s_byslot[my_slot] = my_key;
     }
     __syncthreads();
+    TOPK_STAMP(7);
     // hits ordered by old slot (compaction of s_byslot), misses in selection order
     const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
     const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
@@ -844,6 +933,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_free = s_hvals;  // the hash values are dead after the classification: r-th free slot (ascending)
     if (dst_slots && tid < S && !is_hit_slot) s_free[tid - hit_incl] = tid;
     __syncthreads();
+    TOPK_STAMP(8);
     const int cnt = s_out[4], nm = s_out[5];
     // misses ordered by chunk id: usually sorted already (ascending landmark slot, increasing slot -> id map)
     const int unsorted_here = (tid > 0 && tid < nm && s_miss[tid - 1] > s_miss[tid]) ? 1 : 0;
@@ -863,6 +953,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     } else if (tid < nm) {
         s_rank[tid] = tid;        // read back by the same thread below
     }
+    TOPK_STAMP(9);
     // ---- write out
     if (dst_slots) {
         if (tid < nm) {
@@ -872,6 +963,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
             dst_slots[(size_t)b * S + cnt + r] = slot;
         }
         if (tid == 0) cnts[b] = cnt;
+        TOPK_STAMP(10);
         return;
     }
     if (is_hit_slot) {
@@ -950,11 +1042,11 @@ template <int SEGV>
 static int launch_topk2(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
                         int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
                         int SP, hipStream_t st) {
-    const size_t smem = (size_t)((T2_BINS / 2) * T2_COPIES + SP * 4 + H * 2 + 80 + 16) * sizeof(int);
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 6 + H * 2 + 80 + 16) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)skv_topk2_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)((T2_BINS / 2) * T2_COPIES + 1024 * 4 + 4096 * 2 + 96) * sizeof(int))) != hipSuccess)
+                                (int)((size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96) * sizeof(int))) != hipSuccess)
             return SKV_ERR_LAUNCH;
         attr_set = true;
     }

@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/prof.sh <tag> [bench args...]
+# rocprofv3 kernel trace of a short bench run; condensed per-kernel table -> gpurun_out/<tag>_kernel_stats.txt
+tag=$1; shift
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-extras --no-cpu-baseline "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_prof.log
+f=$(find $out -name '*kernel_stats.csv' | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --no-cpu-baseline $*"; python3 tools/summarize_rocprof.py "$f" 45; echo "# bench line under the profiler:"; cat gpurun_out/${tag}_bench.json; } > gpurun_out/${tag}_kernel_stats.txt
+grep -E "skv_|^# total" gpurun_out/${tag}_kernel_stats.txt

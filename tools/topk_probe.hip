@@ -49,9 +49,15 @@ int main(int argc, char** argv) {
         int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
         hipDeviceSynchronize();
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
+#ifdef SKV_TOPK_V1
         const char* names[] = {"stage+hist1(+hash build)", "select1+zero", "hist2", "select2", "count", "scan", "assign+gather", "-", "lookup", "scan2", "sorted-vote", "write"};
-        printf("run %d rc=%d total %.2f us :", it, rc, (st[12] - st[0]) / 100.0);
-        for (int i = 0; i < 12; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
+        const int ns = 12;
+#else
+        const char* names[] = {"loads+init+max", "hist(+hash build)", "fold+scan+thr", "count+scan", "assign", "id-gather", "lookup", "scan3", "sorted-vote", "write"};
+        const int ns = 10;
+#endif
+        printf("run %d rc=%d total %.2f us :", it, rc, (st[ns] - st[0]) / 100.0);
+        for (int i = 0; i < ns; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
         printf("\n");
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
