@@ -296,12 +296,14 @@ SKV_EXPORT int skv_fetch_kv_inplace(const void* U, const void* SV, const void* c
                          long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                          skv_stream_t stream);
 
-/* skv_fetch_kv_inplace plus the attention over every row that is NOT a miss slot, in the same launch: those rows are
- * final before the launch starts, so their split attention pass runs on the CUs the PCIe-bound V fetch leaves idle
- * (records go to attn_workspace: skv_attn_workspace_bytes(bs, q_heads, attn_splits)).  Follow with
- * skv_attn_finish_inplace.  Together they compute exactly what skv_fetch_kv_inplace + skv_sparse_attention compute
- * (flash_attn_with_kvcache at /root/reference/models/base.py:341), with a different order of the f32 sums.
- * rank 160, chunk_size 8, q_heads / heads in {4, 8}. */
+/* skv_fetch_kv_inplace plus the attention, in the same launch: (1) extra workgroups run the split attention pass over
+ * every row that is NOT a miss slot - those rows are final before the launch starts, so they ride on the CUs the
+ * PCIe-bound V fetch leaves idle; (2) every workgroup that builds a miss tile (8 chunks: K rebuilt, V fetched by the same
+ * workgroup, host loads issued first) attends its 64 rows from LDS before it exits.  Records go to attn_workspace:
+ * skv_attn_workspace_bytes(bs, q_heads, attn_splits + select_sets / 8).  Follow with skv_attn_finish_inplace.  Together
+ * they compute exactly what skv_fetch_kv_inplace + skv_sparse_attention compute (flash_attn_with_kvcache at
+ * /root/reference/models/base.py:341), with a different order of the f32 sums.  rank 160, chunk_size 8, select_sets % 8
+ * == 0, q_heads / heads in {4, 8}; kv_rows = rows per head in the caches (device-side kv_len is clamped to it). */
 SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
@@ -310,12 +312,10 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, float scale, skv_stream_t stream);
 
-/* Attention over the miss rows (one workgroup per query head) merged with the records of the split pass above;
- * out [bs][q_heads][head_dim] bf16. */
-SKV_EXPORT int skv_attn_finish_inplace(const void* q, const void* k_cache, const void* v_cache, const void* attn_workspace,
-                            const int32_t* dst_slots, const int32_t* cnts, void* out, int batch_size, int q_heads,
-                            int kv_heads, int select_sets, long long kv_head_stride, int sparse_start, int attn_splits,
-                            float scale, skv_stream_t stream);
+/* Merge of the records skv_fetch_kv_attn_inplace left (resident splits + live miss tiles, told by cnts);
+ * out [bs][q_heads][128] bf16. */
+SKV_EXPORT int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,
+                            int kv_heads, int select_sets, int attn_splits, skv_stream_t stream);
 
 /* End of a decode step in one launch: top-p filter over the k <= 64 sorted top-k logits (vals = logits / temperature,
  * descending; idx their token ids), multinomial draw (sample_token, /root/reference/models/tensor_op.py:242-297) written

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshadowkv_hip.so")
+LIB_PATH = os.environ.get("SKV_LIB_PATH") or os.path.join(_HERE, "libshadowkv_hip.so")   # override: diagnostic builds only
 
 _lib = None
 
@@ -40,7 +40,7 @@ _SIGS = {
     "skv_select_chunks_inplace": (c_int, [c_p] * 10 + [c_int] * 4 + [c_f, c_p]),
     "skv_fetch_kv_inplace": (c_int, [c_p] * 9 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
     "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 10 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_f, c_p]),
-    "skv_attn_finish_inplace": (c_int, [c_p] * 7 + [c_int] * 4 + [c_ll] + [c_int] * 2 + [c_f, c_p]),
+    "skv_attn_finish_inplace": (c_int, [c_p] * 3 + [c_int] * 5 + [c_p]),
     "skv_sample_advance": (c_int, [c_p] * 2 + [c_int] * 2 + [c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p]),
     "skv_select_from_scores": (c_int, [c_p, c_int] + [c_p] * 6 + [c_int] * 3 + [c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),

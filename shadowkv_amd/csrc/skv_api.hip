@@ -29,9 +29,8 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp,
                        long long v_host_stride, long long v_stride, long long v_off, hipStream_t st,
                        const AttnLaunch* attn);
-int skv_launch_attn_finish(const void* q, const void* k, const void* v, const void* ws, const int32_t* dst_slots,
-                           const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, long long kv_stride_h,
-                           int sparse_start, int rec_splits, float scale, hipStream_t st);
+int skv_launch_attn_merge(const void* ws, const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, int splits,
+                          hipStream_t st);
 int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
                           const int32_t* cnts, long long stride_elems, long long off_elems, int B, int S,
                           hipStream_t st);
@@ -342,7 +341,9 @@ int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin
         !attn_workspace)
         return SKV_ERR_ARG;
     if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
-    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits, scale};
+    if (select_sets % 8) return SKV_ERR_UNSUPPORTED;
+    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits + select_sets / 8,
+                  scale};
     return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
@@ -350,14 +351,11 @@ int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin
                                      (long long)sparse_start * head_dim, (hipStream_t)stream, &al));
 }
 
-int skv_attn_finish_inplace(const void* q, const void* k_cache, const void* v_cache, const void* attn_workspace,
-                            const int32_t* dst_slots, const int32_t* cnts, void* out, int batch_size, int q_heads,
-                            int kv_heads, int select_sets, long long kv_head_stride, int sparse_start, int attn_splits,
-                            float scale, skv_stream_t stream) {
-    if (!q || !k_cache || !v_cache || !attn_workspace || !dst_slots || !cnts || !out) return SKV_ERR_ARG;
-    return finish(skv_launch_attn_finish(q, k_cache, v_cache, attn_workspace, dst_slots, cnts, out, batch_size, q_heads,
-                                         kv_heads, select_sets, kv_head_stride, sparse_start, attn_splits, scale,
-                                         (hipStream_t)stream));
+int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,
+                            int kv_heads, int select_sets, int attn_splits, skv_stream_t stream) {
+    if (!attn_workspace || !cnts || !out) return SKV_ERR_ARG;
+    return finish(skv_launch_attn_merge(attn_workspace, cnts, out, batch_size, q_heads, kv_heads, select_sets, attn_splits,
+                                        (hipStream_t)stream));
 }
 
 int skv_stage_hit_chunks(void* k_cache, void* k_temp, void* v_cache, void* v_temp, const int32_t* offsets,

@@ -22,6 +22,27 @@
 #include "skv_common.h"
 #include "skv_attn_body.h"
 
+// Phase stamps for tools/rb_stamps.py (diagnostic build only, -DSKV_RB_STAMPS -> libshadowkv_hip_stamps.so; no stamp
+// executes in the shipped library).  100 MHz wall clock, one row of 8 per workgroup, a buffer nothing else reads.
+#ifdef SKV_RB_STAMPS
+__device__ unsigned long long g_rb_stamps[16 * 128 * 8];
+#define RB_STAMP(i, leader)                                                                                        \
+    do {                                                                                                           \
+        if ((int)threadIdx.x == (leader) && by < 16 && bx < 128)                                                   \
+            g_rb_stamps[((size_t)by * 128 + bx) * 8 + (i)] = wall_clock64();                                       \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int skv_debug_rb_stamps(unsigned long long* out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rb_stamps), sizeof(g_rb_stamps)) != hipSuccess) return -1;
+    if (clear) {
+        static unsigned long long zeros[16 * 128 * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rb_stamps), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define RB_STAMP(i, leader)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -48,8 +69,128 @@ struct AttnRole {
     float scale;
 };
 
+
+// Attention over the 64 rows of ONE freshly built miss tile (in-place layout, attention role present): the workgroup
+// that rebuilt the K rows of 8 miss chunks holds them in LDS and holds the chunks' V rows in REGISTERS (the landing loads:
+// thread (rsub, unit) has 16 B = 8 dims of token unit / 16 of chunk 2k + rsub, i.e. a 16-lane group holds whole V rows),
+// so it attends the tile right there for all G query heads of the KV head and emits one record (acc[128], m, l) per
+// head - the miss rows are never read back from HBM by a second pass.  The scores and softmax weights are computed while
+// the host loads are still in flight; only p * V waits for them.  Same arithmetic as skv_attn_partial_body (one batch of
+// 4 keys per 16-lane group).  Rows below `first_live` are resident (hit) rows: not attended here (the split pass has them).
+template <int G>
+struct TileAttn {
+    float p[4][G], mn[G], lsum[G];
+
+    // phase A: q . k for the group's 4 rows (K tile and q in LDS), softmax weights relative to the group maximum.
+    // vt = thread index among the 256 attention threads (waves 4..7 of the workgroup)
+    __device__ __forceinline__ void scores(const bf16_t* q, const unsigned char* sK, int first_live, float scale, int vt) {
+        const int sub = vt & 15, rsub = vt >> 7, g8 = (vt & 127) >> 4;
+        float qf[G][8];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const u32x4 wq = *reinterpret_cast<const u32x4*>(q + (size_t)g * AT_D + 8 * sub);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qf[g][2 * j] = bf_lo(wq[j]) * scale;
+                qf[g][2 * j + 1] = bf_hi(wq[j]) * scale;
+            }
+        }
+        float sc[4][G];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (2 * k + rsub) * 8 + g8;                 // the row whose V piece this thread loaded as lv[k]
+            const bool alive = r >= first_live;
+            // dead rows hold the un-rotated product of a resident chunk: never let it meet a weight
+            const u32x4 kr = alive ? *reinterpret_cast<const u32x4*>(sK + r * RB_OUT_PITCH + sub * 16) : (u32x4){0u, 0u, 0u, 0u};
+            float kf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bf_lo(kr[j]);
+                kf[2 * j + 1] = bf_hi(kr[j]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float sd = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sd = __builtin_fmaf(qf[g][j], kf[j], sd);
+                sd = row16_tree_sum(sd);
+                sc[k][g] = alive ? sd : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m = fmaxf(m, sc[k][g]);
+            mn[g] = m;
+            float l = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                p[k][g] = sc[k][g] == -INFINITY ? 0.f : __expf(sc[k][g] - m);
+                l += p[k][g];
+            }
+            lsum[g] = l;
+        }
+    }
+
+    // phase B: p * V from the landing registers -> the group's partial (acc[128], m, l) per query head in LDS
+    __device__ __forceinline__ void pv(const u32x4 (&lv)[4], const bool (&lact)[4], float* s_part_raw, int vt) {
+        const int sub = vt & 15, grp = vt >> 4;
+        float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_part_raw);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (lact[k]) {                                      // (dead rows: p == 0, lv[k] is a filler row)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[2 * j] = __builtin_fmaf(p[k][g], bf_lo(lv[k][j]), acc[2 * j]);
+                        acc[2 * j + 1] = __builtin_fmaf(p[k][g], bf_hi(lv[k][j]), acc[2 * j + 1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[j];
+            if (sub == 0) {
+                s_part[grp][g][AT_D] = mn[g];
+                s_part[grp][g][AT_D + 1] = lsum[g];
+            }
+        }
+    }
+};
+
+// merge of the 16 group partials of a tile: one record per query head, all `nthreads` threads of the workgroup
+template <int G>
+__device__ __forceinline__ void skv_tile_merge(const float* s_part_raw, float* __restrict__ rec, size_t rec_stride_g, int tid,
+                                               int nthreads) {
+    const float (*s_part)[G][AT_D + 2] = reinterpret_cast<const float (*)[G][AT_D + 2]>(s_part_raw);
+    for (int o = tid; o < G * AT_D; o += nthreads) {
+        const int g = o / AT_D, d = o % AT_D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
+        float a = 0.f, L = 0.f;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) {
+            const float mr = s_part[r][g][AT_D];
+            const float wgt = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+            a = __builtin_fmaf(s_part[r][g][d], wgt, a);
+            L = __builtin_fmaf(s_part[r][g][AT_D + 1], wgt, L);
+        }
+        float* dst = rec + (size_t)g * rec_stride_g;
+        dst[d] = a;
+        if (d == 0) {
+            dst[AT_D] = M;
+            dst[AT_D + 1] = L;
+        }
+    }
+}
+
 template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/, int KS, int AG = 0 /* attention role: G */>
-__global__ __launch_bounds__(256) void skv_rebuild_kernel(
+__global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
     const bf16_t* __restrict__ U,        // [bs][seq_len][R]
     const bf16_t* __restrict__ SV,       // [bs][heads][128][R]
     const bf16_t* __restrict__ cos_sin,  // [max_pos][cs_stride]
@@ -69,46 +210,64 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     // the remaining CUs and are PCIe-bound.
     int rebuild_tiles, const u32x4* __restrict__ v_host, u32x4* __restrict__ v_buf, const u32x4* __restrict__ v_temp,
     long long v_host_stride_u128, long long v_stride_u128, long long v_off_u128, int land_blocks, AttnRole ar) {
-    if constexpr (AG > 0) if ((int)blockIdx.x >= rebuild_tiles + land_blocks) {
+    // block -> (role index bx, batch*head by).  Attention role present: a 1-D grid, the tiles of ALL heads first and from
+    // the highest tile index down (the live tiles - miss chunks - are the last ones and are the long pole: their host
+    // loads should go out at once), then the split-attention workgroups over the resident rows.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (AG > 0) {
+        const int nbh = (int)gridDim.x / (rebuild_tiles + ar.splits);
+        if (bx < nbh * rebuild_tiles) {
+            by = bx % nbh;
+            bx = rebuild_tiles - 1 - bx / nbh;
+        } else {
+            const int r = bx - nbh * rebuild_tiles;
+            by = r % nbh;
+            bx = rebuild_tiles + r / nbh;
+        }
+    }
+    if constexpr (AG > 0) if (bx >= rebuild_tiles + land_blocks) {
+        if (threadIdx.x >= 256) return;                       // the split pass is a 256-thread body
+        RB_STAMP(0, 0);
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
-        const int bh3 = blockIdx.y, cnt3 = cnts ? cnts[bh3] : 0;
+        const int bh3 = by, cnt3 = cnts ? cnts[bh3] : 0;
         const int kv_len = min(ar.kv_len_dev ? *ar.kv_len_dev : ar.kv_len_host, ar.kv_rows);
         skv_attn_partial_body<AG, true>(
             ar.q, out, reinterpret_cast<const bf16_t*>(v_buf), ar.ws, kv_len, out_stride_h, ar.splits, ar.rec_splits,
-            (int)blockIdx.x - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
+            bx - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
             dst_slots + (size_t)bh3 * S + cnt3, S - cnt3, out_row0, S * C);
+        RB_STAMP(7, 0);
         return;
     }
-    if ((int)blockIdx.x >= rebuild_tiles) {
-        const int bh2 = blockIdx.y, tid2 = threadIdx.x, unit = tid2 & 127, rsub = tid2 >> 7;
+    if (bx >= rebuild_tiles) {
+        const int bh2 = by, tid2 = threadIdx.x, unit = tid2 & 127, rsub = tid2 >> 7;
         const int cnt2 = cnts ? cnts[bh2] : 0;
-        const int blk = blockIdx.x - rebuild_tiles;
+        const int blk = bx - rebuild_tiles;
         u32x4 lv[4];
         bool lact[4];
-#pragma unroll
+        int loffs[4], ldi[4];     // source and destination of the thread's four rows, looked up BEFORE the host loads
+#pragma unroll                    // (loads return in order: a lookup issued behind them would wait for the PCIe round trip)
         for (int k = 0; k < 4; ++k) {
-            const int i = blk * 8 + k * 2 + rsub;
-            lact[k] = false;
-            if (i < S) {
-                const int off = hit_offsets[(size_t)bh2 * S + i];
-                if (i < cnt2) {
-                    if (!dst_slots && off != i) {
-                        lact[k] = true;
-                        lv[k] = v_temp[((long long)bh2 * S + i) * 128 + unit];
-                    }
-                } else {
-                    lact[k] = true;
-                    lv[k] = v_host[(long long)bh2 * v_host_stride_u128 + (long long)off * 128 + unit];
-                }
-            }
+            const int i = min(blk * 8 + k * 2 + rsub, S - 1);
+            loffs[k] = hit_offsets[(size_t)bh2 * S + i];
+            ldi[k] = dst_slots ? dst_slots[(size_t)bh2 * S + i] : i;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = blk * 8 + k * 2 + rsub;
-            if (lact[k]) {
-                const int di = dst_slots ? dst_slots[(size_t)bh2 * S + i] : i;
-                v_buf[(long long)bh2 * v_stride_u128 + v_off_u128 + (long long)di * 128 + unit] = lv[k];
-            }
+            const int off = loffs[k];
+            const bool moved_hit = i < S && i < cnt2 && !dst_slots && off != i;
+            const bool miss = i < S && i >= cnt2;
+            lact[k] = moved_hit || miss;
+            // unconditional load through a selected pointer (a load under `if` is followed by vmcnt(0): the four PCIe
+            // round trips of a thread would be serialised); inactive rows read a valid, unused row of the cache
+            const u32x4* src = miss ? v_host + ((long long)bh2 * v_host_stride_u128 + (long long)off * 128 + unit)
+                               : moved_hit ? v_temp + (((long long)bh2 * S + i) * 128 + unit)
+                                           : v_buf + ((long long)bh2 * v_stride_u128 + v_off_u128 + unit);
+            lv[k] = *src;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (lact[k]) v_buf[(long long)bh2 * v_stride_u128 + v_off_u128 + (long long)ldi[k] * 128 + unit] = lv[k];
         }
         return;
     }
@@ -120,8 +279,8 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sSV = smem;                         // 128 x 336 B
     unsigned char* sOut = smem + RB_D * RB_SV_PITCH;   // 64 x 272 B
-    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
-    const int i0 = blockIdx.x * RB_ROWS;
+    const int bh = by, b = bh / heads, h = bh % heads;
+    const int i0 = bx * RB_ROWS;
     const int total_rows = S * C;
     const int cnt = cnts ? cnts[bh] : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,6 +306,70 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
         }
     }
     if (i0 + RB_ROWS <= cnt * C) return;  // every row of this tile is a resident (hit) row
+
+    // Attention role present (in-place layout, C == 8, S % 8 == 0): waves 4..7 LAND the V chunks of the tile's 8 slots and
+    // attend the finished tile (TileAttn) from those registers; waves 0..3 rebuild the K tile below.
+    constexpr size_t part_bytes = (size_t)AT_GROUPS * (AG > 0 ? AG : 1) * (AT_D + 2) * sizeof(float);
+    // group partials: over the SV staging area (dead after the MFMA phase) when they fit, else behind the K tile and q
+    float* const s_part = reinterpret_cast<float*>(part_bytes <= (size_t)RB_D * RB_SV_PITCH ? smem : sOut + RB_ROWS * RB_OUT_PITCH + AG * 256);
+    const bf16_t* const q_lds = reinterpret_cast<const bf16_t*>(sOut + RB_ROWS * RB_OUT_PITCH);     // [G][128] behind the K tile
+    if constexpr (AG > 0) {
+        float* const rec = ar.ws + ((size_t)bh * AG * ar.rec_splits + ar.splits + bx) * AT_REC;
+        const size_t rec_stride = (size_t)ar.rec_splits * AT_REC;
+        if (tid >= 256) {
+            const int vt = tid - 256, unit = vt & 127, rsub = vt >> 7, jb = i0 / 8;
+            RB_STAMP(0, 256);
+            int loff[4], lslot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = min(jb + 2 * k + rsub, S - 1);
+                loff[k] = hit_offsets[(size_t)bh * S + j];        // miss id (source chunk) and destination slot of the
+                lslot[k] = dst_slots[(size_t)bh * S + j];         // thread's four chunks; stale for j < cnt, unused then
+            }
+            u32x4 qreg = {0u, 0u, 0u, 0u};
+            if (vt < AG * 16) qreg = reinterpret_cast<const u32x4*>(ar.q + (size_t)bh * AG * AT_D)[vt];
+            if (vt < AG * 16) *reinterpret_cast<u32x4*>(sOut + RB_ROWS * RB_OUT_PITCH + vt * 16) = qreg;
+            // (1) the rebuild waves have RECEIVED every global load they need (U fragments, SV, cos / sin, slots): measured
+            // with in-kernel stamps (tools/rb_stamps.py), loads of device memory issued on a CU while host-memory loads of
+            // the same CU are outstanding come back only with them (K tile ready at 24 us instead of 7 us) - so the host
+            // loads go out behind this barrier, and nothing else on this CU (one 512-thread workgroup per CU) touches
+            // global memory until they are back.
+            __syncthreads();
+            u32x4 lv[4];
+            bool lact[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = jb + 2 * k + rsub;
+                lact[k] = j >= cnt && j < S;
+                // unconditional load through a selected pointer: a load under `if` makes hipcc wait vmcnt(0) right behind
+                // it, i.e. one PCIe round trip per chunk; dead chunks read a (valid, unused) row of the device cache instead
+                const u32x4* src = lact[k] ? v_host + ((long long)bh * v_host_stride_u128 + (long long)loff[k] * 128 + unit)
+                                           : v_buf + ((long long)bh * v_stride_u128 + v_off_u128 + unit);
+                lv[k] = *src;
+            }
+            asm volatile("" ::: "memory");
+            RB_STAMP(1, 256);
+            __syncthreads();                                   // (2) accumulators in LDS
+            __syncthreads();                                   // (3) rotated K tile (and q) in LDS
+            RB_STAMP(2, 256);
+            TileAttn<AG> ta;
+            ta.scores(q_lds, sOut, cnt * 8 - i0, ar.scale, vt);                      // the host loads are still in flight
+            RB_STAMP(3, 256);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)                        // V chunks of the live slots into the cache ...
+                if (lact[k]) v_buf[(long long)bh * v_stride_u128 + v_off_u128 + (long long)lslot[k] * 128 + unit] = lv[k];
+#ifdef SKV_RB_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RB_STAMP(4, 256);
+#endif
+            ta.pv(lv, lact, s_part, vt);                       // ... and the same registers feed p * V
+            __syncthreads();                                   // (4)
+            RB_STAMP(5, 256);
+            skv_tile_merge<AG>(s_part, rec, rec_stride, tid, 512);
+            RB_STAMP(6, 256);
+            return;
+        }
+    }
 
     // ---- phase 1: issue every global load this workgroup needs
     // A fragments (gathered U rows)
@@ -178,9 +401,9 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
         const int u = tid + it * 256;
         const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
         evalid[it] = (i < total_rows) && (i >= cnt * C);
-        if (MODE != 0 && evalid[it]) {
-            long long p = chunk_id_at(ids, ids64, (size_t)bh * S + i / C) * C + i % C;
-            if (p < 0 || p >= seq_len) p = 0;   // invalid ids are a caller error; never read outside the table
+        if (MODE != 0) {   // unconditional loads (rows that are not rebuilt read table row 0): no branch, no early wait
+            long long p = i < total_rows ? chunk_id_at(ids, ids64, (size_t)bh * S + i / C) * C + i % C : 0;
+            if (p < 0 || p >= seq_len || !evalid[it]) p = 0;   // invalid ids are a caller error; never read outside the table
             const bf16_t* cs = cos_sin + p * cs_stride;
             if (MODE == 1) {
                 ecos[it] = *reinterpret_cast<const u32x4*>(cs + 8 * c);
@@ -193,6 +416,12 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
             }
         }
     }
+    int edi[EPI_ITERS];        // destination row of the epilogue rows (in-place layout), looked up before the host loads
+#pragma unroll
+    for (int it = 0; it < EPI_ITERS; ++it) {
+        const int i = i0 + (tid + it * 256) / EPI_UNITS;
+        edi[it] = (dst_slots && evalid[it]) ? dst_slots[(size_t)bh * S + i / C] * C + i % C : i;
+    }
     // ---- phase 2: SV -> LDS (rows padded to 336 B: conflict-free 16-row x 16-B fragment reads)
 #pragma unroll
     for (int it = 0; it < SV_ITERS; ++it) {
@@ -202,6 +431,7 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
             *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = svreg[it];
         }
     }
+    if constexpr (AG > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see barrier (1) of the attention waves
     __syncthreads();
 
     // ---- phase 3: MFMA: acc[nb] covers rows wave*16.., columns nb*16..
@@ -233,8 +463,8 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
     for (int it = 0; it < EPI_ITERS; ++it) {
         if (!evalid[it]) continue;
         const int u = tid + it * 256;
-        const int row = u / EPI_UNITS, c = u % EPI_UNITS, i = i0 + row;
-        const int di = dst_slots ? dst_slots[(size_t)bh * S + i / C] * C + i % C : i;
+        const int row = u / EPI_UNITS, c = u % EPI_UNITS;
+        const int di = edi[it];
         bf16_t* orow = out + (size_t)b * out_stride_b + (size_t)h * out_stride_h + (size_t)(out_row0 + di) * out_stride_s;
         if (MODE == 0) {
             *reinterpret_cast<u32x4*>(orow + 8 * c) = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
@@ -252,6 +482,10 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
             }
             *reinterpret_cast<u32x4*>(orow + 8 * c) = o1;
             *reinterpret_cast<u32x4*>(orow + 64 + 8 * c) = o2;
+            if constexpr (AG > 0) {   // the tile attention reads the rotated row (each unit rewrites only what it read)
+                *reinterpret_cast<u32x4*>(sOut + row * RB_OUT_PITCH + c * 16) = o1;
+                *reinterpret_cast<u32x4*>(sOut + row * RB_OUT_PITCH + 128 + c * 16) = o2;
+            }
         } else {
             // GLM: dims 0..63 interleaved pairs (2t, 2t+1) with cos = cs[t], sin = cs[32+t]; 64..127 copied
             u32x4 x = *reinterpret_cast<const u32x4*>(sOut + row * RB_OUT_PITCH + c * 16);
@@ -267,7 +501,14 @@ __global__ __launch_bounds__(256) void skv_rebuild_kernel(
                 }
             }
             *reinterpret_cast<u32x4*>(orow + 8 * c) = o;
+            if constexpr (AG > 0) *reinterpret_cast<u32x4*>(sOut + row * RB_OUT_PITCH + c * 16) = o;
         }
+    }
+    if constexpr (AG > 0) {
+        __syncthreads();                                       // (3) rotated K rows of the tile are in LDS
+        __syncthreads();                                       // (4) the attention waves' group partials are in LDS
+        skv_tile_merge<AG>(s_part, ar.ws + ((size_t)bh * AG * ar.rec_splits + ar.splits + bx) * AT_REC,
+                           (size_t)ar.rec_splits * AT_REC, tid, 512);
     }
 }
 
@@ -292,7 +533,7 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
     int land_blocks = 0;
     if (v_buf) {
         if (!v_host || (!v_temp && !dst_slots) || !hit_offsets || (v_host_stride % 8) || (v_stride % 8) || (v_off % 8)) return SKV_ERR_ARG;
-        land_blocks = (S + 7) / 8;
+        land_blocks = attn ? 0 : (S + 7) / 8;     // attention role: the rebuild tiles land their own V chunks
     }
     AttnRole ar{};
     int attn_g = 0;
@@ -300,7 +541,7 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
     if (attn) {
         // attention role: in-place layout, rank 160, G in {4, 8}, V buffer laid out like the K buffer
         if (!dst_slots || !v_buf || mode == 0 || R != 160 || (attn->G != 4 && attn->G != 8) || attn->splits < 1 ||
-            attn->rec_splits < attn->splits || v_stride != out_stride_h || out_stride_s != RB_D ||
+            C != 8 || S % 8 || attn->rec_splits != attn->splits + tiles || v_stride != out_stride_h || out_stride_s != RB_D ||
             out_stride_b != (long long)heads * out_stride_h || v_off != (long long)out_row0 * RB_D)
             return SKV_ERR_UNSUPPORTED;
         if (attn->kv_rows < out_row0 + S * C || (long long)attn->kv_rows * RB_D > out_stride_h ||
@@ -309,10 +550,18 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
         ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->kv_rows,
                       attn->splits, attn->rec_splits, attn->scale};
         attn_g = attn->G;
-        const size_t need = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float) + 32 * sizeof(uint32_t);
+        // fused tile: SV staging | K tile (| group partials when they do not fit over the SV staging area)
+        const size_t part = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float);
+        smem_all = (size_t)RB_D * RB_SV_PITCH + (size_t)RB_ROWS * RB_OUT_PITCH + (size_t)attn_g * 256 /* q */ +
+                   (part <= (size_t)RB_D * RB_SV_PITCH ? 0 : part);
+        const size_t need = part + 32 * sizeof(uint32_t);     // resident-rows role
         if (need > smem_all) smem_all = need;
     }
-    dim3 grid(tiles + land_blocks + (attn ? attn->splits : 0), bs * heads), block(256);
+    dim3 grid(tiles + land_blocks, bs * heads), block(256);
+    if (attn) {
+        grid = dim3((tiles + attn->splits) * bs * heads, 1);
+        block = dim3(512);
+    }
     if (attn) {
 #define SKV_RBA(M, GG)                                                                                             \
     do {                                                                                                           \

@@ -144,14 +144,28 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
 
 // final (max, 1/sum) of one softmax row from its T tile partials; executed by one full wave.
 // pm / ps point at element [tile 0] of the row, consecutive tiles are `stride` floats apart.
+// The lane-strided accumulation and the reduction tree are part of the arithmetic contract (oracle softmax_finalize);
+// the tree's last two levels are taken through readlanes: ((r0 + r1) + (r2 + r3)) of the four row sums, the value every
+// lane of the shuffle formulation ends with.
 __device__ __forceinline__ void softmax_finalize_wave(const float* pm, const float* ps, int T, int stride,
                                                       int lane, float& m_out, float& inv_out) {
-    float m = -INFINITY;
-    for (int tt = lane; tt < T; tt += 64) m = fmaxf(m, pm[(size_t)tt * stride]);
-    m = wave_max(m);
-    float acc = 0.0f;
-    for (int tt = lane; tt < T; tt += 64) acc = acc + ps[(size_t)tt * stride] * spec_exp(pm[(size_t)tt * stride] - m);
-    float s = wave_tree_sum(acc);
+    float m = -INFINITY, acc = 0.0f;
+    if (T <= 64) {   // one partial per lane: both loads in flight together (one memory round trip for the finals)
+        const bool in = lane < T;
+        const float pmv = in ? pm[(size_t)lane * stride] : -INFINITY;
+        const float psv = in ? ps[(size_t)lane * stride] : 0.0f;
+        m = wave_max_dpp(pmv);
+        if (in) acc = acc + psv * spec_exp(pmv - m);
+    } else {
+        for (int tt = lane; tt < T; tt += 64) m = fmaxf(m, pm[(size_t)tt * stride]);
+        m = wave_max_dpp(m);
+        for (int tt = lane; tt < T; tt += 64) acc = acc + ps[(size_t)tt * stride] * spec_exp(pm[(size_t)tt * stride] - m);
+    }
+    acc = row16_tree_sum(acc);
+    const int x = __float_as_int(acc);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    const float s = (r0 + r1) + (r2 + r3);
     m_out = m;
     inv_out = 1.0f / s;
 }

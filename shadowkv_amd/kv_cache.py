@@ -431,11 +431,11 @@ class ShadowKVCache_CPU:
                                      kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
               "fetch_kv_inplace")
 
-    OVERLAP_SPLITS = 24   # split pass inside the fetch launch; the finish kernel merges them with the miss rows
+    OVERLAP_SPLITS = 24   # split pass over the resident rows inside the fetch launch (+ one record per miss tile)
 
     def can_overlap_attention(self):
-        return (self.rank == 160 and self.chunk_size == 8 and self.head_dim == 128
-                and self.num_key_value_groups in (4, 8) and self.select_sets <= 1024)
+        return (self.rank == 160 and self.chunk_size == 8 and self.head_dim == 128 and self.select_sets % 8 == 0
+                and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 64)
 
     def select_fetch_attend_inplace(self, layer_idx, query_states, cos_sin_cache, kv_len=0, kv_len_dev=None):
         """select_fetch_inplace + sparse attention of one layer with the attention over the already-resident rows
@@ -459,7 +459,7 @@ class ShadowKVCache_CPU:
         L, st = lib(), current_stream_handle()
         bs, Hq, D = q.shape[0], self.num_attention_heads, self.head_dim
         SA = self.OVERLAP_SPLITS
-        ws = tensor_op.attention_workspace(q.device, bs, Hq, SA)
+        ws = tensor_op.attention_workspace(q.device, bs, Hq, SA + self.select_sets // 8)
         check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
                                           ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
                                           ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
@@ -478,9 +478,8 @@ class ShadowKVCache_CPU:
                                           self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA, scale, st),
               "fetch_kv_attn_inplace")
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
-        check(L.skv_attn_finish_inplace(ptr(q), ptr(kbuf), ptr(vbuf), ptr(ws), ptr(self._dst_slots), ptr(self.cnts),
-                                        ptr(out), bs, Hq, self.num_key_value_heads, self.select_sets, kbuf.stride(1),
-                                        self.sparse_start, SA, scale, st), "attn_finish_inplace")
+        check(L.skv_attn_finish_inplace(ptr(ws), ptr(self.cnts), ptr(out), bs, Hq, self.num_key_value_heads,
+                                        self.select_sets, SA, st), "attn_finish_inplace")
         return out
 
     def note_kv_appended(self, incoming=1):
