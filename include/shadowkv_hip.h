@@ -328,6 +328,14 @@ SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int bat
                        int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
                        skv_stream_t stream);
 
+/* skv_sample_advance with the top-k inside: logits bf16 [bs][row_stride] straight from the lm_head (vocab % 8 == 0, vocab
+ * <= 131,072, 16-B aligned rows), exact top-k by value (ties at the k-th value -> lowest token id), then temperature,
+ * top-p, draw and counters as above - one launch for torch.topk + sample_token + the step bookkeeping. */
+SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
+                            float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
+                            int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                            long long slack, long long table_len, skv_stream_t stream);
+
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 
 /* Chunk means (landmark candidates) and per-chunk minimum cosine similarity (outlier score) of the post-RoPE keys,

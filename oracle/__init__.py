@@ -53,6 +53,11 @@ def batch_gemm_softmax(A, B, D, Norm, Sum, Softmax, batch_count, m, n, k, alpha,
                                     _i(batch_count), _i(m), _i(n), _i(k), _f(alpha), _f(beta))
 
 
+def num_threads():
+    """OpenMP threads the oracle's parallel loops run on."""
+    return int(lib().oracle_num_threads())
+
+
 def group_max_topk(P, landmark_idx, blocks, groups, n, topk):
     """P bf16 [blocks, groups, n] -> int64 [blocks, topk] (ascending slot order)."""
     out = torch.empty(blocks, topk, dtype=torch.int64)

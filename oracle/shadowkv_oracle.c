@@ -22,6 +22,7 @@
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp)
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -165,16 +166,17 @@ ORACLE_API void oracle_batch_gemm_softmax(const uint16_t *A, const uint16_t *B, 
                                           float beta) {
     (void)beta;
     int T = (n + 255) / 256;
-#pragma omp parallel for collapse(2) schedule(static)
+    /* three phases like the reference's three launches; every element is computed exactly as in the serial form, the
+     * loops are only spread over (batch, row, tile) so that all host cores take part (cpu_baseline in bench.py) */
+#pragma omp parallel for collapse(3) schedule(static)
     for (int b = 0; b < batch_count; ++b) {
         for (int r = 0; r < m; ++r) {
-            const uint16_t *q = A + ((size_t)b * m + r) * k;
-            const uint16_t *Bb = B + (size_t)b * n * k;
-            uint16_t *Dr = D + ((size_t)b * m + r) * n;
-            uint16_t *Pr = Softmax + ((size_t)b * m + r) * n;
-            float *mt = Norm + (size_t)b * T * m + r; /* [t*m] */
-            float *st = Sum + (size_t)b * T * m + r;
             for (int t = 0; t < T; ++t) {
+                const uint16_t *q = A + ((size_t)b * m + r) * k;
+                const uint16_t *Bb = B + (size_t)b * n * k;
+                uint16_t *Dr = D + ((size_t)b * m + r) * n;
+                float *mt = Norm + (size_t)b * T * m + r; /* [t*m] */
+                float *st = Sum + (size_t)b * T * m + r;
                 int j0 = t * 256, j1 = j0 + 256 < n ? j0 + 256 : n;
                 float mx = -INFINITY;
                 for (int j = j0; j < j1; ++j) {
@@ -187,13 +189,30 @@ ORACLE_API void oracle_batch_gemm_softmax(const uint16_t *A, const uint16_t *B, 
                 mt[(size_t)t * m] = mx;
                 st[(size_t)t * m] = (float)((double)S * (1.0 / 68719476736.0));
             }
-            float mfin, inv;
-            softmax_finalize(mt, st, T, m, &mfin, &inv);
-            for (int j = 0; j < n; ++j) Pr[j] = f2bf(spec_exp(bf2f(Dr[j]) - mfin) * inv);
-            mt[0] = mfin;
-            st[0] = inv;
         }
     }
+    float *fin = (float *)malloc((size_t)batch_count * m * 2 * sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < batch_count; ++b)
+        for (int r = 0; r < m; ++r)
+            softmax_finalize(Norm + (size_t)b * T * m + r, Sum + (size_t)b * T * m + r, T, m,
+                             &fin[((size_t)b * m + r) * 2], &fin[((size_t)b * m + r) * 2 + 1]);
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int b = 0; b < batch_count; ++b)
+        for (int r = 0; r < m; ++r)
+            for (int t = 0; t < T; ++t) {
+                const uint16_t *Dr = D + ((size_t)b * m + r) * n;
+                uint16_t *Pr = Softmax + ((size_t)b * m + r) * n;
+                const float mfin = fin[((size_t)b * m + r) * 2], inv = fin[((size_t)b * m + r) * 2 + 1];
+                int j0 = t * 256, j1 = j0 + 256 < n ? j0 + 256 : n;
+                for (int j = j0; j < j1; ++j) Pr[j] = f2bf(spec_exp(bf2f(Dr[j]) - mfin) * inv);
+            }
+    for (int b = 0; b < batch_count; ++b)
+        for (int r = 0; r < m; ++r) {
+            Norm[(size_t)b * T * m + r] = fin[((size_t)b * m + r) * 2];
+            Sum[(size_t)b * T * m + r] = fin[((size_t)b * m + r) * 2 + 1];
+        }
+    free(fin);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -213,9 +232,10 @@ static int cmp_bf16_desc(const void *a, const void *c) {
 ORACLE_API int oracle_group_max_topk(const uint16_t *P, const int64_t *landmark_idx, int64_t *out,
                                      int blocks, int groups, int n, int topk) {
     if (n < topk) return -1;
-    uint16_t *score = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
-    uint16_t *tmp = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
+#pragma omp parallel for schedule(static)
     for (int b = 0; b < blocks; ++b) {
+        uint16_t *score = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
+        uint16_t *tmp = (uint16_t *)malloc((size_t)n * sizeof(uint16_t));
         const uint16_t *Pb = P + (size_t)b * groups * n;
         for (int j = 0; j < n; ++j) {
             uint16_t mx = Pb[j];
@@ -243,9 +263,9 @@ ORACLE_API int oracle_group_max_topk(const uint16_t *P, const int64_t *landmark_
                 ++w;
             }
         }
+        free(score);
+        free(tmp);
     }
-    free(score);
-    free(tmp);
     return 0;
 }
 
@@ -404,13 +424,14 @@ ORACLE_API void oracle_batch_gather_gemm(const uint16_t *U, const uint16_t *SV,
                                          int batch_size, int heads, int seq_len, int embed_dim,
                                          int rank, int sparse_budget, int chunk_size,
                                          const int32_t *cnts) {
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int b = 0; b < batch_size; ++b) {
         for (int h = 0; h < heads; ++h) {
-            int cnt = cnts ? cnts[b * heads + h] : 0;
-            int first = (cnt * chunk_size / 128) * 128;
-            const int32_t *pid = position_ids + ((size_t)b * heads + h) * (sparse_budget / chunk_size);
-            for (int i = first; i < sparse_budget; ++i) {
+            for (int i = 0; i < sparse_budget; ++i) {
+                int cnt = cnts ? cnts[b * heads + h] : 0;
+                int first = (cnt * chunk_size / 128) * 128;
+                if (i < first) continue;
+                const int32_t *pid = position_ids + ((size_t)b * heads + h) * (sparse_budget / chunk_size);
                 long pos = (long)pid[i / chunk_size] * chunk_size + i % chunk_size;
                 const uint16_t *u = U + ((size_t)b * seq_len + (size_t)pos) * rank;
                 uint16_t *o = output + (((size_t)b * heads + h) * sparse_budget + i) * embed_dim;
@@ -422,6 +443,9 @@ ORACLE_API void oracle_batch_gather_gemm(const uint16_t *U, const uint16_t *SV,
         }
     }
 }
+
+/* threads the parallel loops above run on (bench.py reports it with the cpu_baseline) */
+ORACLE_API int oracle_num_threads(void) { return omp_get_max_threads(); }
 
 /* ------------------------------------------------------------------------- */
 /* a8: RoPE and push into the key cache (kernels/rope_new.cu)                */

@@ -10,6 +10,7 @@
 // generator state, graph-capturable.  One wave per sequence; k <= 64.
 #include "../../include/shadowkv_hip.h"
 #include "skv_common.h"
+#include "skv_select_front.h"
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // lowbias32 finaliser
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -58,6 +59,195 @@ __global__ __launch_bounds__(64) void skv_sample_advance_kernel(
             if (step_idx) step_idx[0] = (step_idx[0] + 1) % table_len;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole end of step in ONE launch, straight from the bf16 logits of the lm_head: exact top-k (k <= 64) of the V
+// logits of a sequence, temperature, top-p, draw, counters.  Replaces torch.topk over [bs, 128256] (83 us sbtopk +
+// radix-sort / partition launches per token at bs = 1; its multi-block path faulted under hipGraph replay for bs > 1) +
+// the f32 conversion and division of the whole logit row.  The selection is the front end of the chunk-selection kernel
+// (skv_select_front.h): the row lives in registers, one 4,096-bin histogram pass finds the k-th largest value, an
+// ordered compaction collects the k winners (ties at the k-th value -> lowest token id; torch.topk leaves that open).
+// Signed bf16 logits are mapped to order-preserving unsigned 16-bit keys first.  One 1,024-thread workgroup per sequence.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bf16x2_to_keys(uint32_t w) {       // x >= 0: x | 0x8000;  x < 0: ~x
+    const uint32_t neg = (w >> 15) & 0x10001u;
+    return w ^ ((neg * 0xffffu) | 0x80008000u);
+}
+__device__ __forceinline__ float key_to_float(int key) {
+    const uint32_t x = (key & 0x8000) ? (uint32_t)(key ^ 0x8000) : (uint32_t)(~key & 0xffff);
+    return __uint_as_float(x << 16);
+}
+
+template <int SEGV>
+__global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
+    const bf16_t* __restrict__ logits, long long row_stride, int V, int k, float inv_temp, float top_p,
+    unsigned long long seed, int64_t* __restrict__ token, int64_t* __restrict__ pos, int64_t* __restrict__ gen,
+    int64_t* __restrict__ row_idx, int32_t* __restrict__ kv_len, int64_t* __restrict__ step_idx, long long base,
+    long long slack, long long table_len) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
+    int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
+    int* s_out = s_w + 80;                            // [16]
+    int* s_cur = s_out + 16;                          // [64] token id per selected position (ascending id)
+    float* s_sv = reinterpret_cast<float*>(s_cur + 64);   // [64] sorted: logit / temperature, descending
+    int* s_si = reinterpret_cast<int*>(s_sv + 64);    // [64] sorted: token id
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    constexpr int NW = 4 * SEGV, NG = (NW + 15) / 16;
+    uint32_t w[NW];
+    const int j0 = tid * SEGV * 8;
+    {
+        const u32x4* gvec = reinterpret_cast<const u32x4*>(logits + (size_t)b * row_stride);
+        const int nvec = V / 8;
+#pragma unroll
+        for (int q = 0; q < SEGV; ++q) {
+            const int vi = tid * SEGV + q;
+            const u32x4 v = vi < nvec ? gvec[vi] : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) w[4 * q + x] = vi < nvec ? bf16x2_to_keys(v[x]) : 0u;   // padding: key 0
+        }
+    }
+    {
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+        for (int q = 0; q < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++q) hz[tid + q * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    int thr, need_eq;
+    t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - V, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+    // flags (keys use all 16 bits here: plain compares), ordered compaction as in skv_topk2_kernel
+    uint32_t mge[NG], mgt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        mge[g] = 0u;
+        mgt[g] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int lo = (int)(w[i] & 0xffffu), hi = (int)(w[i] >> 16);
+        const uint32_t fe = (uint32_t)(lo >= thr) | ((uint32_t)(hi >= thr) << 1), fg = (uint32_t)(lo > thr) | ((uint32_t)(hi > thr) << 1);
+        mge[i / 16] |= fe << (2 * (i % 16));
+        mgt[i / 16] |= fg << (2 * (i % 16));
+    }
+    int cg = 0, ce = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        cg += __builtin_popcount(mgt[g]);
+        ce += __builtin_popcount(mge[g]);
+    }
+    ce = min(ce - cg, need_eq);
+    const int packed = cg | (ce << 10);
+    const int pexcl = block_scan_incl1(packed, s_w + 32, tid) - packed;
+    {
+        int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            uint32_t m = mge[g];
+            while (m) {
+                const int e = __builtin_ctz(m);
+                m &= m - 1;
+                int p = -1;
+                if ((mgt[g] >> e) & 1u) {
+                    p = gt_run + min(eq_run, need_eq);
+                    ++gt_run;
+                } else {
+                    if (eq_run < need_eq) p = gt_run + eq_run;
+                    ++eq_run;
+                }
+                if (p >= 0) s_cur[p] = j0 + g * 32 + e;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- sort the k winners by (value descending, token id ascending): rank by counting, one lane per winner
+    if (tid < 64) {
+        const bool in = lane < k;
+        const int id = in ? s_cur[lane] : 0x7fffffff;
+        // the winner's logit is read back (L2-hot) rather than dug out of the register row by a run-time index
+        const int key = in ? (int)(bf16x2_to_keys((uint32_t)logits[(size_t)b * row_stride + id]) & 0xffffu) : -1;
+        int rank = 0;
+        for (int m = 0; m < k; ++m) {
+            const int ko = __builtin_amdgcn_readlane(key, m), io = __builtin_amdgcn_readlane(id, m);
+            rank += (ko > key) || (ko == key && io < id);
+        }
+        if (in) {
+            s_sv[rank] = key_to_float(key) * inv_temp;
+            s_si[rank] = id;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- top-p, draw, counters: as skv_sample_advance_kernel
+    const long long p0 = pos[b];
+    const float v = lane < k ? s_sv[lane] : -INFINITY;
+    const float mx = wave_max_dpp(v);
+    const float e = lane < k ? __expf(v - mx) : 0.f;
+    const float tot = wave_tree_sum(e);
+    const float p = e / tot;
+    float c = p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(c, o, 64);
+        if (lane >= o) c += n;
+    }
+    const bool keep = lane < k && (top_p <= 0.f || lane == 0 || (c - p) <= top_p);
+    const float pk = keep ? e : 0.f;
+    uint32_t h = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9u * (uint32_t)p0));
+    h = mix32(h ^ (0x85ebca6bu * (uint32_t)(b + 1)) ^ (0xc2b2ae35u * (uint32_t)(lane + 1)) ^ (uint32_t)(p0 >> 32));
+    const float u = ((h >> 8) + 1) * (1.0f / 16777216.0f);
+    const float ex = -__logf(u);
+    const float score = keep ? pk / fmaxf(ex, 1e-30f) : -1.f;
+    const float best = wave_max_dpp(score);
+    const unsigned long long mwin = __ballot(score == best);
+    const int win = __ffsll((long long)mwin) - 1;
+    if (lane == win) token[b] = (int64_t)s_si[lane];
+    if (lane == 0) {
+        pos[b] = p0 + 1;
+        if (b == 0) {
+            const long long g2 = gen[0] + 1;
+            gen[0] = g2;
+            row_idx[0] = base + g2 % slack;
+            kv_len[0] = (int32_t)(base + (g2 + 1 < slack ? g2 + 1 : slack));
+            if (step_idx) step_idx[0] = (step_idx[0] + 1) % table_len;
+        }
+    }
+}
+
+template <int SEGV>
+static int launch_sample_topk(const void* logits, long long row_stride, int V, int bs, int k, float temperature, float top_p,
+                              unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
+                              int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
+                              hipStream_t st) {
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)skv_sample_topk_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return SKV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
+                       V, k, 1.0f / temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
+                       table_len);
+    return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+}
+
+extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
+                                       float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
+                                       int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                                       long long slack, long long table_len, skv_stream_t stream) {
+    if (!logits || !token || !pos || !gen || !row_idx || !kv_len || batch_size < 1 || !(temperature > 0.f)) return SKV_ERR_ARG;
+    if (k < 1 || k > 64 || vocab < k || slack < 1 || (step_idx && table_len < 1)) return SKV_ERR_UNSUPPORTED;
+    if ((vocab % 8) || (row_stride % 8) || (((size_t)logits) & 15) || vocab > T2_THREADS * 16 * 8) return SKV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int per_thread = (vocab / 8 + T2_THREADS - 1) / T2_THREADS;
+#define SKV_ST(SV) launch_sample_topk<SV>(logits, row_stride, vocab, batch_size, k, temperature, top_p, seed, token, pos, gen, \
+                                          row_idx, kv_len, step_idx, base, slack, table_len, st)
+    if (per_thread <= 1) return SKV_ST(1);
+    if (per_thread <= 2) return SKV_ST(2);
+    if (per_thread <= 4) return SKV_ST(4);
+    if (per_thread <= 8) return SKV_ST(8);
+    return SKV_ST(16);
+#undef SKV_ST
 }
 
 extern "C" int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,

@@ -14,6 +14,7 @@
 // Roofline: the scoring kernel streams the landmark table once (B*N*256 bytes, 31.9 MB per
 // layer at the headline config) and is HBM-bound; everything after it touches <= 1.3 MB.
 #include "skv_common.h"
+#include "skv_select_front.h"
 
 #define SKV_TILE 256  // columns per partial tile == the reference's ThreadblockShape::kN
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -262,35 +263,6 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
 #ifndef SKV_SEL_THREADS
 #define SKV_SEL_THREADS 1024
 #endif
-
-// Phase stamps for tools/topk_probe.hip (diagnostic build only, -DSKV_TOPK_STAMPS; no stamp executes in the
-// shipped library).  100 MHz wall clock, written by thread 0 of workgroup 0 to a buffer nothing else reads.
-#ifdef SKV_TOPK_STAMPS
-__device__ unsigned long long g_topk_stamps[24];
-#define TOPK_STAMP(i)                                                                 \
-    do {                                                                              \
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64();   \
-    } while (0)
-#else
-#define TOPK_STAMP(i)
-#endif
-
-// Inclusive integer scans on DPP (no LDS crossbar round trips): within rows of 16 lanes row_shr 1/2/4/8, then
-// row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2-3 (the GFX9 wave64 scan).  Lanes without a source read
-// `old` = 0.
-__device__ __forceinline__ int row16_scan_incl(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    return v;
-}
-__device__ __forceinline__ int wave_scan_incl(int v) {
-    v = row16_scan_incl(v);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
 
 // inclusive scan of two ints per thread over the 1024-thread workgroup (same barriers for both)
 __device__ __forceinline__ void block_scan_incl2(int& a, int& b, int* s_wave /*[32]*/, int tid) {
@@ -625,44 +597,6 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 // Padding (scores past N in the last thread's vectors) is rewritten to key 0 at load and its count is subtracted
 // from the bin of key 0; padding has the highest indices, so the tie rule never reaches it.
 // ---------------------------------------------------------------------------------------
-#define T2_THREADS 1024
-#define T2_BINS 4096
-#define T2_COPIES 4
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
-}
-
-__device__ __forceinline__ int wave_max_i32_dpp(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
-// inclusive scan over the 1,024-thread workgroup, ONE barrier: each wave publishes its total, then re-scans the 16
-// totals on its own lanes 0..15 (DPP row scan) and picks its prefix with a readlane.  s_w[16] must not be rewritten
-// before another barrier.
-__device__ __forceinline__ int block_scan_incl1(int v, int* s_w, int tid) {
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    v = wave_scan_incl(v);
-    if (lane == 63) s_w[wave] = v;
-    __syncthreads();
-    int w = lane < 16 ? s_w[lane] : 0;
-    w = row16_scan_incl(w);
-    const int pre = wave > 0 ? __builtin_amdgcn_readlane(w, wave - 1) : 0;
-    return v + pre;
-}
-
 template <int SEGV>
 __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     const bf16_t* __restrict__ score,      // [B][score_stride] (nullable: then cur_in is used)
@@ -683,7 +617,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_rank = s_miss + SP;                        // [SP]
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     TOPK_STAMP(0);
     constexpr int NW = 4 * SEGV;                      // 32-bit words (two keys each) per thread
     constexpr int NG = (NW + 15) / 16;                // mask registers: 16 words (32 keys) each
@@ -738,88 +672,8 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
                 w[i] = (j < N ? w[i] & 0xffffu : 0u) | (j + 1 < N ? w[i] & 0xffff0000u : 0u);
             }
         }
-        const int n_pad = T2_THREADS * SEGV * 8 - N;   // keys rewritten to 0 (they are histogrammed like any key)
-        uint32_t m2 = w[0];
-#pragma unroll
-        for (int i = 1; i < NW; ++i) m2 = pk_max_u16(m2, w[i]);
-        int kmx = wave_max_i32_dpp((int)max(m2 & 0xffffu, m2 >> 16));
-        if (lane == 0) s_w[64 + wave] = kmx;
-        __syncthreads();                                   // (A) LDS initialised, wave maxima visible
-        TOPK_STAMP(1);
-        int base;
-        {
-            int wm = lane < 16 ? s_w[64 + lane] : 0;
-            base = wave_max_i32_dpp(wm);
-        }
-        char* const hb = reinterpret_cast<char*>(s_hist) + (lane & (T2_COPIES - 1)) * 4;   // this lane's copy
-        int need = S, thr = 0, need_eq = 0;
-        for (int round = 0;; ++round) {
-            // keys in (base - 4095, base] get their own bin (rel = base - key), everything lower shares bin 4095
-            if (round == 0) {      // base is the maximum: every key is <= base
-                const uint32_t base2 = (uint32_t)base * 0x10001u, cap2 = (uint32_t)(T2_BINS - 1) * 0x10001u;
-#pragma unroll
-                for (int i = 0; i < NW; ++i) {
-                    const uint32_t r2 = pk_min_u16(pk_sub_u16(base2, w[i]), cap2);
-                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 & 0xffffu) << 4)), 1);
-                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 >> 16) << 4)), 1);
-                }
-                insert_resident();
-            } else {
-#pragma unroll
-                for (int i = 0; i < NW; ++i)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int val = h ? (int)(w[i] >> 16) : (int)(w[i] & 0xffffu);
-                        if (val <= base) atomicAdd(reinterpret_cast<int*>(hb + (min(base - val, T2_BINS - 1) << 4)), 1);
-                    }
-            }
-            __syncthreads();                               // (B)
-            TOPK_STAMP(2);
-            // fold the copies: thread t owns bins 4t .. 4t+3 (ascending rel = descending key)
-            int c[4];
-            {
-                const u32x4* hw = reinterpret_cast<const u32x4*>(s_hist + (size_t)tid * 4 * T2_COPIES);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const u32x4 w4 = hw[x];
-                    c[x] = (int)((w4[0] + w4[1]) + (w4[2] + w4[3]));
-                }
-                const int relz = min(base, T2_BINS - 1);   // where the padding zeros were counted
-                if ((relz >> 2) == tid) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if ((relz & 3) == x) c[x] -= n_pad;
-                }
-            }
-            const int tot = (c[0] + c[1]) + (c[2] + c[3]);
-            const int incl = block_scan_incl1(tot, s_w + 16 * (round & 1), tid);      // barrier (C)
-            int run = incl - tot;
-            if (run < need && incl >= need) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    if (run < need && run + c[x] >= need) {
-                        s_out[0] = 4 * tid + x;
-                        s_out[1] = run;
-                    }
-                    run += c[x];
-                }
-            }
-            __syncthreads();                               // (D)
-            TOPK_STAMP(3);
-            const int rel_thr = s_out[0], above = s_out[1];
-            if (rel_thr < T2_BINS - 1) {
-                thr = base - rel_thr;
-                need_eq = need - above;
-                break;
-            }
-            // the k-th value lies among the keys <= base - 4095: slide the window (never for softmax scores of one head)
-            need -= above;
-            base -= T2_BINS - 1;
-            u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
-#pragma unroll
-            for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
-            __syncthreads();
-        }
+        int thr, need_eq;
+        t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - N, S, tid, s_hist, s_w, s_out, thr, need_eq, insert_resident);
         // ---- flags of the thread's keys as bit masks: bit 2i + h of word-group g <=> key (i, h) >= thr (mge) / > thr (mgt).
         // keys are < 0x8000, so key + (0x8000 - thr) has bit 15 set iff key >= thr, and the two halves of a word never carry
         // into each other

@@ -1,0 +1,168 @@
+// Front end of the exact top-k selection shared by the chunk-selection kernel (skv_select.hip) and the sampler
+// (skv_sample.hip): DPP scans, the one-barrier block scan, packed 16-bit helpers and the histogram search for the exact
+// k-th largest 16-bit key of a row held in registers.  See skv_topk2_kernel for the design notes.
+#pragma once
+#include "skv_common.h"
+
+// Phase stamps for tools/topk_probe.hip (diagnostic build only, -DSKV_TOPK_STAMPS; no stamp executes in the
+// shipped library).  100 MHz wall clock, written by thread 0 of workgroup 0 to a buffer nothing else reads.
+#ifdef SKV_TOPK_STAMPS
+__device__ unsigned long long g_topk_stamps[24];
+#define TOPK_STAMP(i)                                                                 \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64();   \
+    } while (0)
+#else
+#define TOPK_STAMP(i)
+#endif
+
+// Inclusive integer scans on DPP (no LDS crossbar round trips): within rows of 16 lanes row_shr 1/2/4/8, then
+// row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2-3 (the GFX9 wave64 scan).  Lanes without a source read
+// `old` = 0.
+__device__ __forceinline__ int row16_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v = row16_scan_incl(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+#define T2_THREADS 1024
+#define T2_BINS 4096
+#define T2_COPIES 4
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// inclusive scan over the 1,024-thread workgroup, ONE barrier: each wave publishes its total, then re-scans the 16
+// totals on its own lanes 0..15 (DPP row scan) and picks its prefix with a readlane.  s_w[16] must not be rewritten
+// before another barrier.
+__device__ __forceinline__ int block_scan_incl1(int v, int* s_w, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    v = wave_scan_incl(v);
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    int w = lane < 16 ? s_w[lane] : 0;
+    w = row16_scan_incl(w);
+    const int pre = wave > 0 ? __builtin_amdgcn_readlane(w, wave - 1) : 0;
+    return v + pre;
+}
+
+// Exact k-th largest key (and the tie quota) of the row whose keys the 1,024 threads hold in w[NW] (two 16-bit keys per
+// word; padding already rewritten to key 0, n_pad of them).  thr = the S-th largest key, need_eq = how many keys equal to
+// thr belong to the top S.  round0_extra() runs between the first histogram pass and its barrier (LDS work that overlaps).
+// s_hist [T2_BINS][T2_COPIES] zeroed by the caller before its first barrier; s_w [80], s_out [16] scratch.
+template <int NW, typename F>
+__device__ __forceinline__ void t2_find_threshold(const uint32_t (&w)[NW], const int n_pad, const int S, const int tid,
+                                                  int* s_hist, int* s_w, int* s_out, int& thr, int& need_eq,
+                                                  F round0_extra) {
+    const int lane = tid & 63, wave = tid >> 6;
+    {
+        uint32_t m2 = w[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) m2 = pk_max_u16(m2, w[i]);
+        int kmx = wave_max_i32_dpp((int)max(m2 & 0xffffu, m2 >> 16));
+        if (lane == 0) s_w[64 + wave] = kmx;
+        __syncthreads();                                   // (A) LDS initialised, wave maxima visible
+        TOPK_STAMP(1);
+        int base;
+        {
+            int wm = lane < 16 ? s_w[64 + lane] : 0;
+            base = wave_max_i32_dpp(wm);
+        }
+        char* const hb = reinterpret_cast<char*>(s_hist) + (lane & (T2_COPIES - 1)) * 4;   // this lane's copy
+        int need = S;
+        thr = 0;
+        need_eq = 0;
+        for (int round = 0;; ++round) {
+            // keys in (base - 4095, base] get their own bin (rel = base - key), everything lower shares bin 4095
+            if (round == 0) {      // base is the maximum: every key is <= base
+                const uint32_t base2 = (uint32_t)base * 0x10001u, cap2 = (uint32_t)(T2_BINS - 1) * 0x10001u;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const uint32_t r2 = pk_min_u16(pk_sub_u16(base2, w[i]), cap2);
+                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 & 0xffffu) << 4)), 1);
+                    atomicAdd(reinterpret_cast<int*>(hb + ((r2 >> 16) << 4)), 1);
+                }
+                round0_extra();
+            } else {
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int val = h ? (int)(w[i] >> 16) : (int)(w[i] & 0xffffu);
+                        if (val <= base) atomicAdd(reinterpret_cast<int*>(hb + (min(base - val, T2_BINS - 1) << 4)), 1);
+                    }
+            }
+            __syncthreads();                               // (B)
+            TOPK_STAMP(2);
+            // fold the copies: thread t owns bins 4t .. 4t+3 (ascending rel = descending key)
+            int c[4];
+            {
+                const u32x4* hw = reinterpret_cast<const u32x4*>(s_hist + (size_t)tid * 4 * T2_COPIES);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const u32x4 w4 = hw[x];
+                    c[x] = (int)((w4[0] + w4[1]) + (w4[2] + w4[3]));
+                }
+                const int relz = min(base, T2_BINS - 1);   // where the padding zeros were counted
+                if ((relz >> 2) == tid) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if ((relz & 3) == x) c[x] -= n_pad;
+                }
+            }
+            const int tot = (c[0] + c[1]) + (c[2] + c[3]);
+            const int incl = block_scan_incl1(tot, s_w + 16 * (round & 1), tid);      // barrier (C)
+            int run = incl - tot;
+            if (run < need && incl >= need) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (run < need && run + c[x] >= need) {
+                        s_out[0] = 4 * tid + x;
+                        s_out[1] = run;
+                    }
+                    run += c[x];
+                }
+            }
+            __syncthreads();                               // (D)
+            TOPK_STAMP(3);
+            const int rel_thr = s_out[0], above = s_out[1];
+            if (rel_thr < T2_BINS - 1) {
+                thr = base - rel_thr;
+                need_eq = need - above;
+                break;
+            }
+            // the k-th value lies among the keys <= base - 4095: slide the window (never for softmax scores of one head)
+            need -= above;
+            base -= T2_BINS - 1;
+            u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+            for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+    }
+}

@@ -197,7 +197,7 @@ class DecoderLM:
 
     # --------------------------------------------------------------- fused decode step (MI355X launch sequence)
     @torch.inference_mode()
-    def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None):
+    def forward_fused(self, token, pos, row_idx, kv_len=0, kv_len_dev=None, q_table=None, as_float=True):
         """Same computation as inference() for q_len == 1, with the small ops fused and the step's
         scalars in device memory (graph-capturable): 10 launches per layer at bs == 1 (in-place layout) instead of ~40.
           token [bs,1] int64, pos [bs,1] int64 (RoPE position), row_idx [1] int64 (cache row of the new K/V),
@@ -234,7 +234,7 @@ class DecoderLM:
                                                          layer.gate_up_proj, fuse_silu_mul=True)
             x = tensor_op.linear_decode(act, layer.down_proj)
         _, logits = tensor_op.norm_linear_decode(x, residual, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
-        return logits.float()
+        return logits.float() if as_float else logits        # (the native sampler reads the bf16 row as it is)
 
     def get_ctx(self, input_ids):
         past = self.kv_cache.get_kv_len()
@@ -443,13 +443,25 @@ class GraphDecoder:
         qstep = None
         if self.walk_table is not None:
             qstep = torch.index_select(self.walk_table, 0, self.step_idx)[0]
-        logits = m.forward_fused(self.token, self.pos, self.row_idx, kv_len=0, kv_len_dev=self.kv_len, q_table=qstep)
+        logits = m.forward_fused(self.token, self.pos, self.row_idx, kv_len=0, kv_len_dev=self.kv_len, q_table=qstep,
+                                 as_float=False)
         last = logits[:, -1, :]
-        k = min(self.top_k, last.size(-1)) if self.top_k > 0 else last.size(-1)
+        V = last.size(-1)
+        k = min(self.top_k, V) if self.top_k > 0 else V
+        tlen = self.walk_table.shape[0] if self.walk_table is not None else 1
+        if (self.temperature > 0.0 and k <= 64 and last.is_cuda and last.dtype == torch.bfloat16 and V % 8 == 0
+                and V <= 131072 and last.stride(-1) == 1 and last.stride(0) % 8 == 0 and last.data_ptr() % 16 == 0):
+            # ONE native launch from the bf16 logits: exact top-k, temperature, top-p, draw, every counter of the step
+            check(lib().skv_sample_topk_advance(ptr(last), last.stride(0), V, last.shape[0], k, float(self.temperature),
+                                                float(self.top_p), self.seed, ptr(self.token), ptr(self.pos), ptr(self.gen),
+                                                ptr(self.row_idx), ptr(self.kv_len),
+                                                ptr(self.step_idx) if self.walk_table is not None else 0, self.base,
+                                                self.slack, tlen, current_stream_handle()), "sample_topk_advance")
+            return
+        last = last.float()
         if self.temperature > 0.0 and k <= 64 and last.is_cuda:
             # top-k by torch, then ONE native launch: top-p filter, draw, and every device-side counter of the step
             vals, idx = self._topk(last / self.temperature, k)
-            tlen = self.walk_table.shape[0] if self.walk_table is not None else 1
             check(lib().skv_sample_advance(ptr(vals), ptr(idx), vals.shape[0], k, float(self.top_p), self.seed,
                                            ptr(self.token), ptr(self.pos), ptr(self.gen), ptr(self.row_idx),
                                            ptr(self.kv_len), ptr(self.step_idx) if self.walk_table is not None else 0,

@@ -453,3 +453,62 @@ def test_decode_refuses_to_run_past_the_generated_row_slack():
     torch.cuda.synchronize()
     rows = m3.kv_cache.k_cache_buffer.shape[-2]
     assert int(d3.kv_len) == rows and int(d3.row_idx) == m3.kv_cache.sparse_end + (slack + 7) % slack
+
+
+def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
+    """skv_sample_topk_advance (one launch from the bf16 logit row: exact top-k, temperature, top-p, draw, counters):
+    * k = 1 is the argmax, ties -> lowest token id, negative logits ordered correctly;
+    * every draw is a member of torch.topk's set (rows without ties at the k-th value);
+    * frequencies follow softmax(top-k logits / temperature) with the nucleus rule of sample_token
+      (/root/reference/models/tensor_op.py:242-297): token i kept iff the cumulative probability before it is <= top_p;
+    * the counters advance like skv_sample_advance's."""
+    from shadowkv_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for V in (128256, 32000, 1000 * 8):
+        bs, k = 3, 50
+        x = (torch.randn(bs, V, device=DEV, generator=g) * 2).bfloat16()
+        x[0, 777] = 30.0                                      # row 0: one dominant logit
+        x[2] = -x[2].abs() - 1                                # row 2: every logit negative
+        token = torch.zeros(bs, 1, dtype=torch.long, device=DEV)
+        pos = torch.tensor([[5], [6], [7]], dtype=torch.long, device=DEV)
+        gen = torch.tensor([3], dtype=torch.long, device=DEV); row = torch.zeros(1, dtype=torch.long, device=DEV)
+        kvl = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+        def run(k_, temp, top_p, n):
+            out = []
+            for _ in range(n):
+                _lib.check(L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), V, bs, k_, temp, top_p, 4242, _lib.ptr(token),
+                                                     _lib.ptr(pos), _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1,
+                                                     _lib.current_stream_handle()), "sample_topk_advance")
+                out.append(token.flatten().clone())
+            torch.cuda.synchronize()
+            return torch.stack(out)
+
+        am = run(1, 1.0, 0.0, 2)
+        xf = x.float()
+        mx = xf.max(dim=-1, keepdim=True).values
+        first_max = torch.where(xf == mx, torch.arange(V, device=DEV).expand(bs, -1), V).min(dim=-1).values
+        assert torch.equal(am[0], first_max) and torch.equal(am[1], first_max)
+        draws = run(k, 0.6, 0.9, 600)
+        tv, ti = torch.topk(xf, k, dim=-1)
+        for b_ in range(bs):
+            kth = tv[b_, -1]
+            allowed = set(ti[b_].tolist()) | set((xf[b_] == kth).nonzero().flatten().tolist())
+            assert set(draws[:, b_].tolist()) <= allowed, (V, b_)
+        assert torch.all(draws[:, 0] == 777)                  # p0 > top_p: the nucleus is the dominant token alone
+        # row 1: expected nucleus from torch ops (unique values among the leaders of a randn row at this size)
+        p = torch.softmax(tv[1] / 0.6, dim=-1)
+        keep = torch.cat((torch.ones(1, dtype=torch.bool, device=DEV), torch.cumsum(p, 0)[:-1] <= 0.9))
+        nucleus = set(ti[1][keep].tolist())
+        drawn = set(draws[:, 1].tolist())
+        assert drawn <= nucleus | set((xf[1] == tv[1][keep][-1]).nonzero().flatten().tolist())
+        top_tok = int(ti[1][0])
+        want = float(p[0] / p[keep].sum())
+        got = float((draws[:, 1] == top_tok).float().mean())
+        assert abs(got - want) < 0.08, (got, want)
+        assert pos.flatten().tolist() == [5 + 602, 6 + 602, 7 + 602] and int(gen) == 3 + 602
+        assert int(row) == 2496 + (3 + 602) % 96 and int(kvl) == 2496 + 96
+    # shapes the kernel is not built for are refused, not mis-sampled
+    assert L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), 151552, 1, 50, 0.6, 0.9, 1, _lib.ptr(token), _lib.ptr(pos),
+                                     _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1, 0) == -2
