@@ -13,7 +13,10 @@ no collective on the decode path); aggregate tokens/s = N*
 Weights and context are synthetic (no checkpoints / datasets offline): random bf16 weights in the named
 shapes, context state from shadowkv_amd.llama.build_synthetic_context, per-layer query random walk.
 
-Prints ONE JSON line on rank 0 (metric / roofline / cpu_baseline: see DESIGN.md "Measurement").
+Prints ONE JSON line on rank 0 (metric / roofline / cpu_baseline: see DESIGN.md "Measurement").  Besides the headline
+the line carries (N = 1 only): the chunk hit rate of the TIMED steps, the pinned hit rates 0 % and 60 % (SURVEY.md 8d;
+the reference's own test assumes 154/256, kernels/test_cached_gather_copy.cu:61), the reference slot order
+(`--layout reference`), and short lines for BASELINE.json configs 2 and 3.
 """
 import argparse
 import json
@@ -38,6 +41,8 @@ WORKLOADS = {
     "llama3_1048k_full": ("LLAMA_3_8B_1048K", 1048576, 2048),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PCIE_PEAK_GBS = 63.0    # PCIe Gen5 x16 spec; 57 GB/s measured DMA ceiling (profiles/r01_pcie_probe.txt)
+HEADLINE_METRIC = "decode tokens/sec @122K ctx, Llama-3.1-8B, budget=2048 rank=160; 1/2/4/8 GPU"
 
 
 def aggregate_throughput(tokens_per_rank, elapsed_per_rank):
@@ -65,6 +70,150 @@ def pin_to_gpu_numa_node(local_rank):
         return None
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# model / state
+# ----------------------------------------------------------------------------------------------------------------------
+def build_model(workload, args, rank, dev, layout=None, overlap=None):
+    from shadowkv_amd import llama
+    cfg_name, ctx, budget = WORKLOADS[workload]
+    cfg = getattr(llama, cfg_name)
+    full = args.attn == "full"
+    t0 = time.perf_counter()
+    model = llama.DecoderLM(cfg=cfg, batch_size=args.batch, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
+                            chunk_size=8, num_layers=args.layers, seed=1234 + rank,
+                            attn_mode="full" if full else "shadowkv_cpu",
+                            chunk_layout=layout or args.layout, v_offload=args.v_table == "host",
+                            overlap_attention=bool(args.overlap_attention if overlap is None else overlap),
+                            max_new_tokens=max(1024, 4 * (args.warmup + args.steps) + 256))
+    if full:
+        llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
+    else:
+        llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
+    torch.cuda.synchronize()
+    return model, cfg, ctx, budget, time.perf_counter() - t0
+
+
+def rewind(model, ctx):
+    """Back to the state right after the prefill (generated rows are simply overwritten by the next run)."""
+    c = model.kv_cache
+    c.kv_offset = ctx
+    if model.attn_mode != "full":
+        c.gen_offset = 0
+
+
+def pinned_eviction(model, pin):
+    """Pre-step hook that pins the chunk hit rate: the query is constant (the selection T never changes), and before
+    every step round((1 - pin) * S) resident ids of every head are overwritten by ids outside T, so exactly pin * S of
+    the selected chunks are found resident.  One strided copy per step, captured with it."""
+    c = model.kv_cache
+    S = c.select_sets
+    n_evict = S - int(round(pin * S))
+    if n_evict == 0:
+        return None
+    T = c.position_ids                                             # [L, bs, kv, S] = the current selection
+    idx = c.k_landmark_idx                                         # [L, bs, kv, N] chunk id per landmark slot
+    present = torch.zeros(idx.shape[:-1] + (int(idx.max()) + 2,), dtype=torch.bool, device=idx.device)
+    present.scatter_(-1, T.clamp_min(0), True)
+    outside = ~present.gather(-1, idx)                             # landmark slots whose chunk is NOT selected
+    take = outside & (outside.cumsum(-1) <= n_evict)
+    filler = idx.masked_select(take).view(idx.shape[:-1] + (n_evict,)).contiguous()
+    view = c.position_ids[..., :n_evict]
+    return lambda: view.copy_(filler)
+
+
+def run_decode(model, args, ctx, steps, warmup, walk_step, seed, world=1, pin_hit=None):
+    """warmup + exactly `steps` timed decode steps (barrier + synchronize on both sides, MAX over ranks).
+    Returns dict(value, ms_per_step, hit_rate (of the timed steps), mode, slack_ring)."""
+    from shadowkv_amd import llama
+    cache, cfg = model.kv_cache, model.cfg
+    full = model.attn_mode == "full"
+    bs = model.batch_size
+    dev = model.device
+    rewind(model, ctx)
+    slack = (cache.k_cache.shape[-2] - ctx) if full else (cache.k_cache_buffer.shape[-2] - cache.sparse_end)
+    slack_ring = warmup + steps + 3 > slack
+    next_token = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
+    walk = llama.QueryWalk(model, step=walk_step, seed=seed)
+    dec = None
+    if args.mode == "graph":
+        table = None
+        if args.query_mode == "walk":
+            table = llama.make_walk_table(model, warmup + steps + 6, step=0.0 if pin_hit is not None else walk_step, seed=seed)
+        # more steps than generated-row slack (96 rows at 122K): the rows become a ring (bench only; "slack_ring")
+        dec = llama.GraphDecoder(model, temperature=0.6, walk_table=table, ring_slack=slack_ring)
+        dec.token.copy_(next_token)
+        try:
+            if pin_hit is not None:
+                dec._check_room(); dec._body(); dec._host_advance()       # resident set := selection of the constant query
+                torch.cuda.synchronize()
+                dec.pre_step = pinned_eviction(model, pin_hit)
+            dec.capture()
+        except Exception as e:            # a headline measured in another launch mode than asked for is not a result
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); --mode eager runs without a graph",
+                  file=sys.stderr)
+            sys.exit(3)
+    hits_eager = torch.zeros((), device=dev, dtype=torch.float64)
+
+    def step():
+        nonlocal next_token
+        if dec is not None:
+            next_token = dec.step()
+        else:
+            if full:
+                if cache.kv_offset - ctx >= slack:
+                    cache.kv_offset = ctx
+            elif cache.gen_offset >= slack:           # generated-token slack exhausted: the reference silently drops
+                cache.gen_offset = 0                  # further rows; rewind the bookkeeping so every step does full work
+                cache.kv_offset = ctx
+            if args.query_mode == "walk":
+                walk.advance()
+            next_token = model.decode_step(next_token, temperature=0.6,
+                                           q_table=walk.qb if args.query_mode == "walk" else None)
+            if not full:
+                hits_eager.add_(cache._cnts_layers.sum())
+        return next_token[:, -1].tolist()             # per-step host sync, as base.py:635
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    h0 = int(dec.hit_accum) if dec is not None else float(hits_eager)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    h1 = int(dec.hit_accum) if dec is not None else float(hits_eager)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    hit_rate = None
+    if not full:
+        hit_rate = (h1 - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets)
+    return dict(value=aggregate_throughput([steps * bs] * world, [elapsed]), ms_per_step=elapsed / steps * 1e3,
+                hit_rate=hit_rate, mode=args.mode, slack_ring=slack_ring)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# roofline / path-only / CPU baseline
+# ----------------------------------------------------------------------------------------------------------------------
 def measure_score_kernel(model, iters=3):
     """HIP-event timing of the dominant hand-written kernel (landmark scan, skv_score_tile_kernel) on
     torch's current stream, cycling over all layers' landmark tables (1 GB >> Infinity Cache)."""
@@ -99,29 +248,33 @@ def measure_score_kernel(model, iters=3):
                 gbs=alg_bytes / us * 1e-3)
 
 
-def measure_path_only(model, walk, steps=8):
-    """The ShadowKV kernels of one token alone (per layer: select -> [stage hits] -> K rebuild || V fetch -> attention;
-    dense layers excluded), captured in a hipGraph like the full step.  Returns (ms per token, chunk hit rate)."""
+def measure_path_only(model, walk_step, steps=8):
+    """The ShadowKV kernels of one token alone (per layer: select -> K rebuild || V fetch || attention; dense layers
+    excluded), captured in a hipGraph like the full step.  Returns (ms per token, chunk hit rate of those steps)."""
     from shadowkv_amd import llama, tensor_op
     cache = model.kv_cache
     dev = model.device
-    table = llama.make_walk_table(model, steps + 2, step=walk.step, seed=4242)
+    table = llama.make_walk_table(model, steps + 2, step=walk_step, seed=4242)
     step_idx = torch.zeros(1, dtype=torch.long, device=dev)
-    hits = torch.zeros((), device=dev, dtype=torch.float32)
+    hits = torch.zeros((), device=dev, dtype=torch.float64)
     kv_len = torch.tensor([cache.sparse_end + 1], dtype=torch.int32, device=dev)
+    overlap = model.chunk_layout == "inplace" and model.overlap_attention and cache.can_overlap_attention()
 
     def one_token():
         q_all = torch.index_select(table, 0, step_idx)[0]
         for l in range(model.num_layers):
             q = q_all[l]
+            if overlap:
+                cache.select_fetch_attend_inplace(l, q, model.cos_sin_cache, kv_len=0, kv_len_dev=kv_len)
+                continue
             if model.chunk_layout == "inplace":
                 cache.select_fetch_inplace(l, q, model.cos_sin_cache)
             else:
                 ids = cache.get_retrieval_position_ids(layer_idx=l, query_states=q)
                 cache.fetch_kv(l, ids, model.cos_sin_cache)
-            hits.add_(cache.cnts.sum())
             tensor_op.sparse_attention_decode(q, cache.k_cache_buffer[l], cache.v_cache_buffer[l], kv_len=0,
                                               kv_len_dev=kv_len)
+        hits.add_(cache._cnts_layers.sum())
         step_idx.copy_((step_idx + 1) % table.shape[0])
 
     s = torch.cuda.Stream(device=dev)
@@ -145,72 +298,91 @@ def measure_path_only(model, walk, steps=8):
     return dt * 1e3, hit_rate
 
 
-def cpu_baseline(model, walk, sample_layers=4, sample_steps=4):
-    """The oracle (CPU restatement, OpenMP) timed on this box's host cores for the ShadowKV path of
-    `sample_layers` layers x `sample_steps` tokens, plus torch-CPU bf16 F.linear for one layer's dense
-    weights; extrapolated to the full model.  A reported baseline, not a target."""
+def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=30.0):
+    """The oracle (CPU restatement, C / OpenMP, loops spread over tiles and rows so every host core takes part) timed
+    on this box's host cores: the ShadowKV path of ALL layers' state for `warm` + `timed` decode steps (fewer if a step
+    takes so long that the sample would exceed ~budget_s), plus torch-CPU bf16 F.linear over one layer's dense
+    weights (1 + 3 repetitions), scaled to the model's layers + lm_head.  A reported baseline, not a target."""
     import oracle
+    from shadowkv_amd import llama
     cache, cfg = model.kv_cache, model.cfg
     kv, G, D, C, S = cache.num_key_value_heads, cache.num_key_value_groups, cache.head_dim, cache.chunk_size, cache.select_sets
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
-    sample_layers = min(sample_layers, model.num_layers)
-    path_s = 0.0
-    for l in range(sample_layers):
-        lm = cache.k_landmark[l][0].cpu().contiguous(); lm_idx = cache.k_landmark_idx[l][0].cpu().contiguous()
-        N = lm.shape[1]; T = (N + 255) // 256
-        U = cache.U[l].cpu().contiguous(); SV = cache.SV[l].cpu().contiguous()
-        pos = cache.position_ids[l][0].cpu().clone()
-        kbuf = cache.k_cache_buffer[l].cpu().clone(); vbuf = cache.v_cache_buffer[l].cpu().clone()
+    threads = oracle.num_threads()
+    torch.set_num_threads(os.cpu_count())
+    L = model.num_layers
+    walk = llama.QueryWalk(model, step=walk_step, seed=777)
+    cs = model.cos_sin_cache.cpu()
+    st = []
+    for l in range(L):                                   # host mirror of every layer's state (copied once, untimed)
         vhost = cache.v_cache_cpu[l][0]
-        if vhost.is_cuda:                      # --v-table hbm
-            vhost = vhost.cpu()
-        rows = kbuf.shape[2]
-        cs = model.cos_sin_cache.cpu()
-        qs = []
-        for _ in range(sample_steps):
-            walk.advance()
-            qs.append(walk.qb[l].cpu().view(kv, G, D).contiguous())
-        Dm = torch.zeros(kv, G, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
-        nm = torch.zeros(kv, T, G); sm = torch.zeros(kv, T, G)
-        off = torch.zeros(kv, S, dtype=torch.int32); cnt = torch.zeros(kv, dtype=torch.int32)
-        pre = torch.zeros(1, kv, S * C, D, dtype=torch.bfloat16)
-        t0 = time.perf_counter()
-        for q in qs:
-            oracle.batch_gemm_softmax(q, lm, Dm, nm, sm, P, kv, G, N, D, 1.0 / math.sqrt(128))
-            sel = oracle.group_max_topk(P, lm_idx, kv, G, N, S)
-            oracle.reorder_keys_and_compute_offsets(pos, sel, off, cnt, 1, kv, S)
-            oracle.gather_copy_with_offsets(vhost, vbuf[0], None, off, cnt, None, 1, kv, vhost.stride(0), S * C * D,
-                                            cache.sparse_start * D, rows * D, S)
-            oracle.gather_copy_d2d_with_offsets(kbuf[0], off, cnt, 1, kv, S * C * D, cache.sparse_start * D, rows * D, S)
-            ids32 = pos.to(torch.int32).view(1, kv, S).contiguous()
-            oracle.batch_gather_gemm(U, SV, None, None, ids32, pre, 1, kv, U.shape[1], D, cache.rank, S * C, 0, C, cnt)
+        st.append(dict(lm=cache.k_landmark[l][0].cpu().contiguous(), lm_idx=cache.k_landmark_idx[l][0].cpu().contiguous(),
+                       U=cache.U[l].cpu().contiguous(), SV=cache.SV[l].cpu().contiguous(),
+                       pos=cache.position_ids[l][0].cpu().clone(), kbuf=cache.k_cache_buffer[l].cpu().clone(),
+                       vbuf=cache.v_cache_buffer[l].cpu().clone(), vhost=vhost.cpu() if vhost.is_cuda else vhost))
+    N = st[0]["lm"].shape[1]
+    T = (N + 255) // 256
+    rows = st[0]["kbuf"].shape[2]
+    Dm = torch.zeros(kv, G, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
+    nm = torch.zeros(kv, T, G); sm = torch.zeros(kv, T, G)
+    off = torch.zeros(kv, S, dtype=torch.int32); cnt = torch.zeros(kv, dtype=torch.int32)
+    pre = torch.zeros(1, kv, S * C, D, dtype=torch.bfloat16)
+    rope = oracle.apply_rotary_pos_emb_push_cache_opt_glm if cfg.rope_style == "glm" else oracle.apply_rotary_pos_emb_push_cache_opt
+
+    def one_step():
+        walk.advance()
+        qb = walk.qb.cpu()
+        for l in range(L):
+            s_ = st[l]
+            q = qb[l].view(kv, G, D).contiguous()
+            oracle.batch_gemm_softmax(q, s_["lm"], Dm, nm, sm, P, kv, G, N, D, 1.0 / math.sqrt(128))
+            sel = oracle.group_max_topk(P, s_["lm_idx"], kv, G, N, S)
+            oracle.reorder_keys_and_compute_offsets(s_["pos"], sel, off, cnt, 1, kv, S)
+            oracle.gather_copy_with_offsets(s_["vhost"], s_["vbuf"][0], None, off, cnt, None, 1, kv, s_["vhost"].stride(0),
+                                            S * C * D, cache.sparse_start * D, rows * D, S)
+            oracle.gather_copy_d2d_with_offsets(s_["kbuf"][0], off, cnt, 1, kv, S * C * D, cache.sparse_start * D, rows * D, S)
+            ids32 = s_["pos"].to(torch.int32).view(1, kv, S).contiguous()
+            oracle.batch_gather_gemm(s_["U"], s_["SV"], None, None, ids32, pre, 1, kv, s_["U"].shape[1], D, cache.rank, S * C, 0, C, cnt)
+            kb = s_["kbuf"]
             ints = (1, kv, S * C, D, pre.stride(0), pre.stride(1), pre.stride(2), 1, cs.stride(0), ids32.stride(0),
-                    ids32.stride(1), ids32.stride(2), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
+                    ids32.stride(1), ids32.stride(2), kb.stride(0), kb.stride(1), kb.stride(2),
                     cache.sparse_start, cache.sparse_end, 64, C)
-            (oracle.apply_rotary_pos_emb_push_cache_opt_glm if cfg.rope_style == "glm"
-             else oracle.apply_rotary_pos_emb_push_cache_opt)(pre, cs, ids32, kbuf, cnt, *ints)
-            oracle.sparse_attention(q.view(1, kv * G, D), kbuf, vbuf, cache.sparse_end + 1, 1.0 / math.sqrt(D))
-        path_s += time.perf_counter() - t0
-    path_ms_layer = path_s / (sample_layers * sample_steps) * 1e3
-    # dense layers on the CPU: one layer's weights, bf16 F.linear
+            rope(pre, cs, ids32, kb, cnt, *ints)
+            oracle.sparse_attention(q.view(1, kv * G, D), kb, s_["vbuf"], cache.sparse_end + 1, 1.0 / math.sqrt(D))
+
+    t0 = time.perf_counter()
+    one_step()
+    first = time.perf_counter() - t0
+    warm_done = 1
+    while warm_done < warm and first * (warm_done + 1) < budget_s / 3:
+        one_step(); warm_done += 1
+    n_timed = max(1, min(timed, int((budget_s - first * warm_done) / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n_timed):
+        one_step()
+    path_ms_token = (time.perf_counter() - t0) / n_timed * 1e3
+    # dense layers on the CPU: one layer's weights, bf16 F.linear, 1 warm + 3 timed repetitions
     lay = model.layers[0]
     w = [lay.wqkv.cpu(), lay.wo.cpu(), lay.gate_up_proj.cpu(), lay.down_proj.cpu()]
     x = torch.randn(1, 1, cfg.hidden_size).bfloat16(); xi = torch.randn(1, 1, cfg.intermediate_size).bfloat16()
-    for _ in range(2):
+    reps = []
+    for _ in range(4):
         t0 = time.perf_counter()
         torch.nn.functional.linear(x, w[0]); torch.nn.functional.linear(x, w[1])
         torch.nn.functional.linear(x, w[2]); torch.nn.functional.linear(xi, w[3])
-        dense_ms_layer = (time.perf_counter() - t0) * 1e3
+        reps.append((time.perf_counter() - t0) * 1e3)
+    dense_ms_layer = sum(reps[1:]) / 3
     head_ms = dense_ms_layer * (cfg.vocab_size * cfg.hidden_size) / sum(t.numel() for t in w)
-    ms_token = (path_ms_layer + dense_ms_layer) * cfg.num_hidden_layers + head_ms
-    return dict(value=round(1e3 / ms_token, 4), unit="tokens/s", cores=cores, kind="port",
-                sample=(f"oracle (C/OpenMP) ShadowKV path of {sample_layers} layers x {sample_steps} tokens "
-                        f"({path_ms_layer:.1f} ms/layer) + torch-CPU bf16 dense of 1 layer ({dense_ms_layer:.1f} ms), "
-                        f"extrapolated to {cfg.num_hidden_layers} layers + lm_head"),
-                path_ms_per_layer=round(path_ms_layer, 2), dense_ms_per_layer=round(dense_ms_layer, 2))
+    ms_token = path_ms_token + dense_ms_layer * L + head_ms
+    return dict(value=round(1e3 / ms_token, 4), unit="tokens/s", cores=os.cpu_count(), threads_used=threads,
+                cpu_model=cpu_model_name(), kind="port",
+                sample=(f"oracle (C/OpenMP, {threads} threads) ShadowKV path over all {L} layers' state, {warm_done} warm-up + "
+                        f"{n_timed} timed decode steps ({path_ms_token:.0f} ms/token = {path_ms_token / L:.1f} ms/layer) + torch-CPU bf16 "
+                        f"dense of 1 layer, 1 + 3 repetitions ({dense_ms_layer:.1f} ms/layer) scaled to {L} layers + lm_head"),
+                path_ms_per_token=round(path_ms_token, 1), path_ms_per_layer=round(path_ms_token / L, 2),
+                dense_ms_per_layer=round(dense_ms_layer, 2), timed_steps=n_timed)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,14 +400,17 @@ def main():
                     help="slot order of the resident chunk set: the reference's (hits compacted to the front) or "
                          "in place (hits keep their slots; same chunk set, no hit movement)")
     ap.add_argument("--overlap-attention", type=int, default=1, choices=[0, 1],
-                    help="in-place layout: attention over the resident rows runs inside the fetch launch")
+                    help="in-place layout: attention runs inside the fetch launch (resident rows + the miss tiles)")
     ap.add_argument("--v-table", default="host", choices=["host", "hbm"],
                     help="where the chunked V table lives: pinned host memory (the headline configuration, the "
                          "reference's offload) or HBM (8 GB per sequence; not the headline metric)")
     ap.add_argument("--query-mode", default="walk", choices=["walk", "model"])
     ap.add_argument("--walk-step", type=float, default=0.3)
+    ap.add_argument("--pin-hit-rate", type=float, default=None,
+                    help="constant query + forced evictions: exactly this fraction of the selected chunks is resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,110 +428,47 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
-    from shadowkv_amd import llama
-    cfg_name, ctx, budget = WORKLOADS[args.workload]
-    cfg = getattr(llama, cfg_name)
-    t_build = time.perf_counter()
     full = args.attn == "full"
     bs = args.batch
-    model = llama.DecoderLM(cfg=cfg, batch_size=bs, max_length=ctx, device=dev, sparse_budget=budget, rank=160,
-                            chunk_size=8, num_layers=args.layers, seed=1234 + rank,
-                            attn_mode="full" if full else "shadowkv_cpu", chunk_layout=args.layout,
-                            v_offload=args.v_table == "host", overlap_attention=bool(args.overlap_attention),
-                            max_new_tokens=max(1024, args.warmup + args.steps + 64))
-    if bs > 1:
-        args.no_cpu_baseline = True
-    if full:
-        llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
-        args.no_extras = True
-        args.no_cpu_baseline = True
-    else:
-        llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
-    walk = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
+    model, cfg, ctx, budget, t_build = build_model(args.workload, args, rank, dev)
     cache = model.kv_cache
-    slack = (cache.k_cache.shape[-2] - ctx) if full else (cache.k_cache_buffer.shape[-2] - cache.sparse_end)
-    t_build = time.perf_counter() - t_build
-    slack_ring = args.warmup + args.steps + 2 > slack
+    head = run_decode(model, args, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, world=world,
+                      pin_hit=args.pin_hit_rate)
 
-    next_token = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
-    tokens = []
-    mode = args.mode
-    dec = None
-    if mode == "graph":
-        table = None
-        if args.query_mode == "walk":
-            table = llama.make_walk_table(model, args.warmup + args.steps + 4, step=args.walk_step, seed=99 + rank)
-        # more steps than generated-row slack (96 rows at 122K): the rows become a ring (bench only; "slack_ring" below)
-        dec = llama.GraphDecoder(model, temperature=0.6, walk_table=table, ring_slack=slack_ring)
-        dec.token.copy_(next_token)
-        try:
-            dec.capture()
-        except Exception as e:            # a headline measured in another launch mode than asked for is not a result
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); --mode eager runs without a graph",
-                  file=sys.stderr)
-            sys.exit(3)
-
-    def step():
-        nonlocal next_token
-        if dec is not None:
-            next_token = dec.step()
-        else:
-            if full:
-                if cache.kv_offset - ctx >= slack:
-                    cache.kv_offset = ctx
-            elif cache.gen_offset >= slack:           # generated-token slack (96 rows at 122K) exhausted: the
-                cache.gen_offset = 0                  # reference silently drops further rows; rewind the
-                cache.kv_offset = ctx                 # bookkeeping instead so every step does full work
-            if args.query_mode == "walk":
-                walk.advance()
-            next_token = model.decode_step(next_token, temperature=0.6,
-                                           q_table=walk.qb if args.query_mode == "walk" else None)
-        tokens.append(next_token[:, -1].tolist())     # per-step host sync, as base.py:635
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_max = float(t)
-    else:
-        elapsed_max = elapsed
-    value = aggregate_throughput([args.steps * bs] * world, [elapsed_max])
-    ms_per_step = elapsed_max / args.steps * 1e3
-
-    out = None
     if rank == 0:
-        from shadowkv_amd import _lib
-        roof = measure_score_kernel(model) if not full else None
         extras = {}
-        if not args.no_extras:
-            path_ms, hit_rate = measure_path_only(model, walk)
+        detail = world == 1 and not args.no_extras and not full
+        roof = measure_score_kernel(model) if not full else None
+        if detail:
+            path_ms, path_hit = measure_path_only(model, args.walk_step)
             wbytes = model.weight_bytes()
             B, N = cache.block_num, cache.k_landmark.shape[-2]
-            miss = 1.0 - hit_rate
+            miss = 1.0 - path_hit
             path_bytes = model.num_layers * (B * N * 256 + B * cache.select_sets * 8
                                               + miss * B * budget * (cache.rank * 2 + 2 * 256) + B * 128 * cache.rank * 2
                                               + 2 * B * cache.sparse_end * 256)
-            extras = dict(path_ms_per_step=round(path_ms, 3), chunk_hit_rate=round(hit_rate, 4),
+            pcie_gbs = miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9
+            extras = dict(path_ms_per_step=round(path_ms, 3), path_chunk_hit_rate=round(path_hit, 4),
                           weight_bytes=wbytes, path_algorithmic_bytes=int(path_bytes),
-                          step_hbm_frac_of_peak=round((wbytes + path_bytes) / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                          step_hbm_frac_of_peak=round((wbytes + path_bytes) / (head["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                           path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
-                          pcie_gbs_in_path=round(miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9, 2),
-                          state_build_s=round(t_build, 1), numa_node=numa, query_mode=args.query_mode, launch_mode=mode,
-                          slack_ring=slack_ring,
-                          walk_step=args.walk_step)
+                          pcie_gbs_in_path=round(pcie_gbs, 2), pcie_frac_of_spec=round(pcie_gbs / PCIE_PEAK_GBS, 3))
+            short = dict(steps=24, warmup=4)
+            if args.pin_hit_rate is None and args.mode == "graph" and args.query_mode == "walk":
+                sweep = []
+                for pin in (0.0, 0.6):            # the pinned extremes next to the walk's measured rate
+                    r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=7, pin_hit=pin)
+                    sweep.append(dict(pinned_hit_rate=pin, measured_hit_rate=round(r["hit_rate"], 4),
+                                      value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]))
+                extras["hit_rate_sweep"] = sweep
+            if args.layout == "inplace":          # the reference's slot order (hits compacted to the front), no overlap
+                # (same state: "slot i holds chunk position_ids[i]" is the invariant of both layouts)
+                model.chunk_layout, model.overlap_attention = "reference", False
+                r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                extras["value_reference_layout"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                        chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
+                                                        note="--layout reference --overlap-attention 0: the reference's slot order bit for bit")
+                model.chunk_layout, model.overlap_attention = "inplace", bool(args.overlap_attention)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
         if os.path.exists(pmc_path) and args.workload == "llama31_122k":
@@ -365,25 +477,41 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": ("decode tokens/sec @122K ctx, Llama-3.1-8B, budget=2048 rank=160; 1/2/4/8 GPU"
-                       if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}")
+            "metric": (HEADLINE_METRIC if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}")
             if not full else f"decode tokens/sec, FULL-ATTENTION baseline, {args.workload}",
-            "value": round(value, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(head["value"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
                                    f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
-                                   + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)"),
+                                   + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)")
+                                   + ("" if args.pin_hit_rate is None else f" (chunk hit rate pinned to {args.pin_hit_rate})"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
+            "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
+            "launch_mode": head["mode"], "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
+            "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa,
         }
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; static file, not re-measured in this run)",
                                "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
                                "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, walk)
+        if world == 1 and bs == 1 and not full and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args.walk_step)
+        if detail and not args.no_secondary and args.workload == "llama31_122k" and bs == 1 and args.layers is None:
+            import gc
+            sec = []
+            for wl in ("llama3_1048k_131072", "glm4_200k"):       # BASELINE.json configs 2 and 3, short runs
+                model = cache = None
+                gc.collect(); torch.cuda.empty_cache()
+                model, cfg2, ctx2, budget2, tb = build_model(wl, args, rank, dev)
+                r = run_decode(model, args, ctx2, 24, 4, args.walk_step, seed=99 + rank)
+                sec.append(dict(workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
+                                value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1)))
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

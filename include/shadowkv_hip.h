@@ -321,12 +321,14 @@ SKV_EXPORT int skv_attn_finish_inplace(const void* attn_workspace, const int32_t
  * descending; idx their token ids), multinomial draw (sample_token, /root/reference/models/tensor_op.py:242-297) written
  * to token[bs], and the device-side step counters advanced: pos[b] += 1; gen += 1 (tokens generated so far); row_idx =
  * base + gen % slack; kv_len = base + min(gen + 1, slack); step_idx = (step_idx + 1) % table_len (step_idx nullable).
- * (gen < slack is the regular case; beyond it the generated rows are a ring of the last `slack` tokens.)  Randomness: counter-based hash of
+ * (gen < slack is the regular case; beyond it the generated rows are a ring of the last `slack` tokens.)
+ * Statistics (optional, hit_accum NULL = off): hit_accum[0] += sum of hit_cnts[0 .. n_hit_cnts) - the chunk hit counts the
+ * selection kernels of this step left (all layers), so a captured step counts its own hits without extra launches.  Randomness: counter-based hash of
  * (seed, pos[b], b, lane) - reproducible and graph-capturable. */
 SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,
                        unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
                        int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
-                       skv_stream_t stream);
+                       const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, skv_stream_t stream);
 
 /* skv_sample_advance with the top-k inside: logits bf16 [bs][row_stride] straight from the lm_head (vocab % 8 == 0, vocab
  * <= 131,072, 16-B aligned rows), exact top-k by value (ties at the k-th value -> lowest token id), then temperature,
@@ -334,7 +336,8 @@ SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int bat
 SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
                             float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
                             int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
-                            long long slack, long long table_len, skv_stream_t stream);
+                            long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                            int64_t* hit_accum, skv_stream_t stream);
 
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 

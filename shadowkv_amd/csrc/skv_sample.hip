@@ -21,7 +21,8 @@ __global__ __launch_bounds__(64) void skv_sample_advance_kernel(
     const float* __restrict__ vals, const int64_t* __restrict__ idx, int k, float top_p, unsigned long long seed,
     int64_t* __restrict__ token /*[bs]*/, int64_t* __restrict__ pos /*[bs]*/, int64_t* __restrict__ gen /*[1]*/,
     int64_t* __restrict__ row_idx /*[1]*/, int32_t* __restrict__ kv_len /*[1]*/, int64_t* __restrict__ step_idx /*[1]*/,
-    long long base, long long slack, long long table_len) {
+    long long base, long long slack, long long table_len, const int32_t* __restrict__ hit_cnts, int n_hit_cnts,
+    int64_t* __restrict__ hit_accum) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const long long p0 = pos[b];
     const float v = lane < k ? vals[(size_t)b * k + lane] : -INFINITY;
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(64) void skv_sample_advance_kernel(
     const unsigned long long m = __ballot(score == best);
     const int win = __ffsll((long long)m) - 1;
     if (lane == win) token[b] = idx[(size_t)b * k + lane];
+    if (b == 0 && hit_accum != nullptr) {                 // statistics: chunk hits of this step (all layers' cnts)
+        int hsum = 0;
+        for (int i = lane; i < n_hit_cnts; i += 64) hsum += hit_cnts[i];
+        hsum = wave_sum_i32(hsum);
+        if (lane == 0) hit_accum[0] += hsum;
+    }
     if (lane == 0) {
         pos[b] = p0 + 1;
         if (b == 0) {                                     // gen counts generated tokens; past the slack the rows form a
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     const bf16_t* __restrict__ logits, long long row_stride, int V, int k, float inv_temp, float top_p,
     unsigned long long seed, int64_t* __restrict__ token, int64_t* __restrict__ pos, int64_t* __restrict__ gen,
     int64_t* __restrict__ row_idx, int32_t* __restrict__ kv_len, int64_t* __restrict__ step_idx, long long base,
-    long long slack, long long table_len) {
+    long long slack, long long table_len, const int32_t* __restrict__ hit_cnts, int n_hit_cnts,
+    int64_t* __restrict__ hit_accum) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
@@ -200,6 +208,12 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     const unsigned long long mwin = __ballot(score == best);
     const int win = __ffsll((long long)mwin) - 1;
     if (lane == win) token[b] = (int64_t)s_si[lane];
+    if (b == 0 && hit_accum != nullptr) {                 // statistics: chunk hits of this step (all layers' cnts)
+        int hsum = 0;
+        for (int i = lane; i < n_hit_cnts; i += 64) hsum += hit_cnts[i];
+        hsum = wave_sum_i32(hsum);
+        if (lane == 0) hit_accum[0] += hsum;
+    }
     if (lane == 0) {
         pos[b] = p0 + 1;
         if (b == 0) {
@@ -216,7 +230,7 @@ template <int SEGV>
 static int launch_sample_topk(const void* logits, long long row_stride, int V, int bs, int k, float temperature, float top_p,
                               unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
                               int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
-                              hipStream_t st) {
+                              const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, hipStream_t st) {
     const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
@@ -227,21 +241,22 @@ static int launch_sample_topk(const void* logits, long long row_stride, int V, i
     }
     hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
                        V, k, 1.0f / temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
-                       table_len);
+                       table_len, hit_cnts, n_hit_cnts, hit_accum);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
 
 extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
                                        float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
                                        int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
-                                       long long slack, long long table_len, skv_stream_t stream) {
+                                       long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                                       int64_t* hit_accum, skv_stream_t stream) {
     if (!logits || !token || !pos || !gen || !row_idx || !kv_len || batch_size < 1 || !(temperature > 0.f)) return SKV_ERR_ARG;
     if (k < 1 || k > 64 || vocab < k || slack < 1 || (step_idx && table_len < 1)) return SKV_ERR_UNSUPPORTED;
     if ((vocab % 8) || (row_stride % 8) || (((size_t)logits) & 15) || vocab > T2_THREADS * 16 * 8) return SKV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int per_thread = (vocab / 8 + T2_THREADS - 1) / T2_THREADS;
 #define SKV_ST(SV) launch_sample_topk<SV>(logits, row_stride, vocab, batch_size, k, temperature, top_p, seed, token, pos, gen, \
-                                          row_idx, kv_len, step_idx, base, slack, table_len, st)
+                                          row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum, st)
     if (per_thread <= 1) return SKV_ST(1);
     if (per_thread <= 2) return SKV_ST(2);
     if (per_thread <= 4) return SKV_ST(4);
@@ -253,10 +268,11 @@ extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride,
 extern "C" int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,
                                   unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
                                   int32_t* kv_len, int64_t* step_idx, long long base, long long slack,
-                                  long long table_len, skv_stream_t stream) {
+                                  long long table_len, const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum,
+                                  skv_stream_t stream) {
     if (!vals || !idx || !token || !pos || !gen || !row_idx || !kv_len || batch_size < 1) return SKV_ERR_ARG;
     if (k < 1 || k > 64 || slack < 1 || (step_idx && table_len < 1)) return SKV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(skv_sample_advance_kernel, dim3(batch_size), dim3(64), 0, (hipStream_t)stream, vals, idx, k, top_p,
-                       seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack, table_len);
+                       seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }

@@ -163,7 +163,10 @@ class ShadowKVCache_CPU:
 
         self.block_num = bs * kv
         self.offsets = torch.zeros(self.block_num * self.select_sets, device=self.device, dtype=torch.int32)
-        self.cnts = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)
+        # hit counts: one row per layer (a decode step leaves every layer's counts behind: statistics, and the captured
+        # step can sum them in its last kernel); `cnts` - the reference's attribute - is the row of the layer being processed
+        self._cnts_layers = torch.zeros(L, self.block_num, device=self.device, dtype=torch.int32)
+        self.cnts = self._cnts_layers[0]
         self.signals = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)   # reference attribute; unused
         self.position_ids = torch.full((L, bs, kv, self.select_sets), -1, device=self.device, dtype=torch.int64)
         self._select_ws = None
@@ -336,6 +339,7 @@ class ShadowKVCache_CPU:
         Returns position_ids[layer_idx] (reordered in place: hits by old slot, then misses by id);
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
+        self.cnts = self._cnts_layers[layer_idx]
         if self.incoming_q_len != 1:
             raise ValueError("decode-time selection expects q_len == 1 (the reference's top-k over "
                              "view(bs, kv, G, -1) is only meaningful for q_len == 1, kv_cache.py:1023-1035)")
@@ -408,6 +412,7 @@ class ShadowKVCache_CPU:
         if query_states.shape[-2] != 1:
             raise ValueError("decode-time selection expects q_len == 1")
         self.incoming_q_len = 1
+        self.cnts = self._cnts_layers[layer_idx]
         lm = self.k_landmark[layer_idx]
         if self._select_ws is None:
             self.H2D()
@@ -450,6 +455,7 @@ class ShadowKVCache_CPU:
             raise ValueError(f"kv_len {kv_len} outside ({self.sparse_end}, {buf_rows}]: the generated-row slack is "
                              f"{buf_rows - self.sparse_end} rows")
         self.incoming_q_len = 1
+        self.cnts = self._cnts_layers[layer_idx]
         lm = self.k_landmark[layer_idx]
         if self._select_ws is None:
             self.H2D()

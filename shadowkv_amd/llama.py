@@ -402,6 +402,9 @@ class GraphDecoder:
         self.walk_table = walk_table                     # [T, L, bs, Hq, 1, D] or None
         self._zero = torch.zeros((), device=dev, dtype=model.dtype)
         self.graph = None
+        self.pre_step = None          # optional callable run at the start of every (captured) step - benchmarks
+        # chunk hits of all steps so far (summed inside the step's last kernel from the per-layer hit counts)
+        self.hit_accum = torch.zeros(1, dtype=torch.long, device=dev)
 
     def _sample(self, logits):
         """Same distribution as tensor_op.sample_token (top-k 50 -> top-p 0.9 -> multinomial): after the top-k
@@ -438,8 +441,16 @@ class GraphDecoder:
         v2, i2 = torch.topk(v1.reshape(bs, parts * k), k, dim=-1)
         return v2, i1.reshape(bs, parts * k).gather(-1, i2)
 
+    def _hit_args(self):
+        c = self.m.kv_cache
+        if self.full:
+            return 0, 0, 0
+        return ptr(c._cnts_layers), c._cnts_layers.numel(), ptr(self.hit_accum)
+
     def _body(self):
         m, c = self.m, self.m.kv_cache
+        if self.pre_step is not None:
+            self.pre_step()
         qstep = None
         if self.walk_table is not None:
             qstep = torch.index_select(self.walk_table, 0, self.step_idx)[0]
@@ -456,7 +467,8 @@ class GraphDecoder:
                                                 float(self.top_p), self.seed, ptr(self.token), ptr(self.pos), ptr(self.gen),
                                                 ptr(self.row_idx), ptr(self.kv_len),
                                                 ptr(self.step_idx) if self.walk_table is not None else 0, self.base,
-                                                self.slack, tlen, current_stream_handle()), "sample_topk_advance")
+                                                self.slack, tlen, *self._hit_args(), current_stream_handle()),
+                  "sample_topk_advance")
             return
         last = last.float()
         if self.temperature > 0.0 and k <= 64 and last.is_cuda:
@@ -465,7 +477,8 @@ class GraphDecoder:
             check(lib().skv_sample_advance(ptr(vals), ptr(idx), vals.shape[0], k, float(self.top_p), self.seed,
                                            ptr(self.token), ptr(self.pos), ptr(self.gen), ptr(self.row_idx),
                                            ptr(self.kv_len), ptr(self.step_idx) if self.walk_table is not None else 0,
-                                           self.base, self.slack, tlen, current_stream_handle()), "sample_advance")
+                                           self.base, self.slack, tlen, *self._hit_args(), current_stream_handle()),
+                  "sample_advance")
             return
         self.token.copy_(self._sample(last))
         # advance the device-side counters (same arithmetic as skv_sample_advance)
@@ -475,6 +488,8 @@ class GraphDecoder:
         self.kv_len.copy_((self.gen + 1).clamp(max=self.slack).add(self.base).to(torch.int32))
         if self.walk_table is not None:
             self.step_idx.copy_((self.step_idx + 1) % self.walk_table.shape[0])
+        if not self.full:
+            self.hit_accum.add_(c._cnts_layers.sum())
 
     def _host_advance(self):
         c = self.m.kv_cache

@@ -346,13 +346,15 @@ def test_sample_advance_kernel_distribution_and_counters():
     pos = torch.tensor([[10], [20], [30]], dtype=torch.long, device=DEV)
     gen = torch.tensor([93], dtype=torch.long, device=DEV); row = torch.zeros(1, dtype=torch.long, device=DEV)
     kvl = torch.zeros(1, dtype=torch.int32, device=DEV); step = torch.tensor([5], dtype=torch.long, device=DEV)
+    hits_in = torch.arange(300, dtype=torch.int32, device=DEV); hits = torch.zeros(1, dtype=torch.long, device=DEV)
 
     def run(vals, top_p, n):
         out = []
         for _ in range(n):
             _lib.check(L.skv_sample_advance(_lib.ptr(vals), _lib.ptr(idx), bs, k, top_p, 77, _lib.ptr(token), _lib.ptr(pos),
                                             _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), _lib.ptr(step), 2496, 96, 7,
-                                            _lib.current_stream_handle()), "sample_advance")
+                                            _lib.ptr(hits_in), hits_in.numel(), _lib.ptr(hits), _lib.current_stream_handle()),
+                       "sample_advance")
             out.append(token.flatten().clone())
         torch.cuda.synchronize()
         return torch.stack(out)
@@ -378,6 +380,7 @@ def test_sample_advance_kernel_distribution_and_counters():
     run(vals.contiguous(), 0.9, 1)
     assert int(gen) == 11 and int(row) == 2496 + 11 and int(kvl) == 2496 + 12
     assert int(step) == (5 + 2001) % 7
+    assert int(hits) == 2001 * sum(range(300))                                # statistics: cnts summed once per step
     # top_p = 0 disables the nucleus filter: the tail (p ~ 1e-14) is still never drawn, the four tokens are
     draws = run(vals.contiguous(), 0.0, 200)
     assert (draws[:, 1] - 1050).max() <= 3
@@ -480,7 +483,7 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
             for _ in range(n):
                 _lib.check(L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), V, bs, k_, temp, top_p, 4242, _lib.ptr(token),
                                                      _lib.ptr(pos), _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1,
-                                                     _lib.current_stream_handle()), "sample_topk_advance")
+                                                     0, 0, 0, _lib.current_stream_handle()), "sample_topk_advance")
                 out.append(token.flatten().clone())
             torch.cuda.synchronize()
             return torch.stack(out)
@@ -511,4 +514,4 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
         assert int(row) == 2496 + (3 + 602) % 96 and int(kvl) == 2496 + 96
     # shapes the kernel is not built for are refused, not mis-sampled
     assert L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), 151552, 1, 50, 0.6, 0.9, 1, _lib.ptr(token), _lib.ptr(pos),
-                                     _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1, 0) == -2
+                                     _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1, 0, 0, 0, 0) == -2
