@@ -351,7 +351,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     }
     auto insert_resident = [&]() __attribute__((always_inline)) {
         if (tid < S && my_cached >= 0) {
-            unsigned pos = (unsigned)my_cached & (unsigned)(H - 1);
+            unsigned pos = hash_slot(my_cached, H);
             for (int probe = 0; probe < H; ++probe) {
                 int prev = atomicCAS(&s_hkeys[pos], -1, my_cached);
                 if (prev == -1 || prev == my_cached) {
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
     int my_slot = -1;
     if (tid < S) {
         if (my_key >= 0) {
-            unsigned pos = (unsigned)my_key & (unsigned)(H - 1);
+            unsigned pos = hash_slot(my_key, H);
             for (int probe = 0; probe < H; ++probe) {
                 int k2 = s_hkeys[pos];
                 if (k2 == my_key) {
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     }
     auto insert_resident = [&]() __attribute__((always_inline)) {
         if (tid < S && my_cached >= 0) {
-            unsigned pos = (unsigned)my_cached & (unsigned)(H - 1);
+            unsigned pos = hash_slot(my_cached, H);
             for (int probe = 0; probe < H; ++probe) {
                 int prev = atomicCAS(&s_hkeys[pos], -1, my_cached);
                 if (prev == -1 || prev == my_cached) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int my_slot = -1;
     if (tid < S) {
         if (my_key >= 0) {
-            unsigned pos = (unsigned)my_key & (unsigned)(H - 1);
+            unsigned pos = hash_slot(my_key, H);
             for (int probe = 0; probe < H; ++probe) {
                 int k2 = s_hkeys[pos];
                 if (k2 == my_key) {
