@@ -471,7 +471,7 @@ def main():
                 model.chunk_layout, model.overlap_attention = "inplace", bool(args.overlap_attention)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
-        if os.path.exists(pmc_path) and args.workload == "llama31_122k":
+        if os.path.exists(pmc_path) and args.workload == "llama31_122k" and bs == 1:
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
@@ -498,6 +498,10 @@ def main():
                                "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
                                "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
         out.update(extras)
+        if bs == 24 and args.workload == "llama31_122k" and not full:
+            # context only (other hardware, the reference's own batch regime): never a vs_baseline
+            out["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100", "batch": 24,
+                                                     "source": "index.html:210-214 (config test/e2e.py:63-68)"}
         if world == 1 and bs == 1 and not full and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args.walk_step)
         if detail and not args.no_secondary and args.workload == "llama31_122k" and bs == 1 and args.layers is None:

@@ -252,8 +252,9 @@ SKV_EXPORT int skv_silu_and_mul(const void* x, void* out, int rows, int inter, s
 SKV_EXPORT int skv_gemv_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                   skv_stream_t stream);
 
-/* The same projection for M <= 16 token rows (batched decode, bs sequences x q_len 1): X [M][K], Y [M][N] (or [M][N/2]
- * with fuse_silu_mul); the weights stream once, the tokens ride the MFMA N dimension.  K % 32 == 0.  Agrees with
+/* The same projection for M <= 32 token rows (batched decode, bs sequences x q_len 1): X [M][K], Y [M][N] (or [M][N/2]
+ * with fuse_silu_mul); the weights stream once, the tokens ride the MFMA N dimension (two 16-token tiles per weight
+ * fragment for M > 16).  K % 32 == 0.  Agrees with
  * M calls of skv_gemv_bf16 to f32 accumulation error (different summation order), not bit for bit. */
 SKV_EXPORT int skv_linear_rows_bf16(const void* W, const void* X, const void* bias, void* Y, int M, int N, int K,
                          int fuse_silu_mul, skv_stream_t stream);

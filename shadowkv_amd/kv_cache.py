@@ -32,6 +32,7 @@ Beyond the reference's surface (opt-in, used by DecoderLM.forward_fused / bench.
   * v_offload=False keeps the chunked V table in HBM; svd_mode="gram" factorises through K^T K;
     prefill_kv_cache computes chunk means / outlier scores in one native pass when the keys are on the GPU.
 """
+import ctypes
 import gc
 import math
 
@@ -39,6 +40,34 @@ import torch
 
 from . import tensor_op
 from ._lib import lib, check, ptr, current_stream_handle
+
+
+class _PinnedHostBuffer:
+    """Exact-size page-locked, device-mapped host allocation (hipHostMalloc) for the chunked V table.  torch's caching
+    pinned allocator rounds every request up to a power of two (8.19 GB -> 16 GiB per 122K-token sequence; the
+    reference's batch of 24 sequences, 197 GB, would ask for 256 GiB); the V table is allocated once and lives as long
+    as the cache, so it bypasses that allocator.  `tensor()` is a zero-copy CPU view; torch recognises the memory as
+    pinned (hipPointerGetAttributes), so GPU -> host copies into it are asynchronous DMA."""
+    _hip = None
+
+    def __init__(self, nbytes):
+        if _PinnedHostBuffer._hip is None:
+            _PinnedHostBuffer._hip = ctypes.CDLL("libamdhip64.so")
+        p = ctypes.c_void_p()
+        rc = self._hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes), ctypes.c_uint(0))
+        if rc != 0 or not p.value:
+            raise MemoryError(f"hipHostMalloc({nbytes} bytes) failed with error {rc}")
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def tensor(self, shape, dtype):
+        t = torch.frombuffer((ctypes.c_char * self.nbytes).from_address(self.ptr), dtype=dtype).view(shape)
+        t._skv_owner = self                      # the view keeps the allocation alive
+        return t
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._hip.hipHostFree(ctypes.c_void_p(self.ptr))
+            self.ptr = None
 
 
 class KV_Cache:
@@ -105,8 +134,14 @@ def gram_factorize(k, rank):
     lam_r = lam[:, -rank:].flip(-1).clamp_min(0)
     v_r = vec[:, :, -rank:].flip(-1)                                        # [bs, H, rank], descending s
     s_r = lam_r.sqrt()
-    u_r = torch.matmul(k, v_r) / s_r.clamp_min(torch.finfo(torch.float32).tiny).unsqueeze(1)
-    return u_r, v_r.transpose(1, 2) * s_r.unsqueeze(-1)
+    # directions whose singular value is numerically zero (K of rank < `rank`, or below the f32 resolution of the Gram
+    # matrix: eigenvalues are accurate to ~eps * lambda_max, i.e. singular values to ~sqrt(eps) * s_max) carry nothing but
+    # rounding noise: their U column is set to 0 instead of noise / ~0 (the matching SV row is ~0 either way), so the
+    # product stays the best approximation of the given rank and never holds inf / NaN
+    keep = s_r > s_r[:, :1] * (torch.finfo(torch.float32).eps ** 0.5) * 4
+    inv = torch.where(keep, 1.0 / s_r.clamp_min(torch.finfo(torch.float32).tiny), torch.zeros_like(s_r))
+    u_r = torch.matmul(k, v_r) * inv.unsqueeze(1)
+    return u_r, v_r.transpose(1, 2) * (s_r * keep).unsqueeze(-1)
 
 
 class ShadowKVCache_CPU:
@@ -143,9 +178,12 @@ class ShadowKVCache_CPU:
         # with v_offload=False, HBM (what the reference's GPU-resident ShadowKVCache does, kv_cache.py:155-506: the
         # same kernels then gather the misses at HBM speed; 8 GB per 122K-token sequence of the 288 GB)
         self.v_offload = bool(v_offload) or not on_gpu
-        if self.v_offload:
-            self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype,
-                                           pin_memory=on_gpu)
+        if self.v_offload and on_gpu:
+            shape = (L, bs, kv, max_length // C, D * C)
+            self._v_host = _PinnedHostBuffer(math.prod(shape) * 2)
+            self.v_cache_cpu = self._v_host.tensor(shape, dtype).zero_()
+        elif self.v_offload:
+            self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype)
         else:
             self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device=self.device, dtype=dtype)
         buf_len = self.sparse_budget + 128 + (self.outlier_chunk + self.local_chunk) * C

@@ -35,7 +35,7 @@ def silu_and_mul(out, x):
     return out
 
 
-MAX_GEMV_ROWS = 16   # token rows served by the native kernels (1: GEMV, 2..16: small-M MFMA kernel); more -> F.linear
+MAX_GEMV_ROWS = 32   # token rows served by the native kernels (1: GEMV, 2..32: small-M MFMA kernel); more -> F.linear
 
 
 def linear_decode(x, w, bias=None, fuse_silu_mul=False):

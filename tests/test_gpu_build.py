@@ -2,6 +2,8 @@
 /root/reference/models/kv_cache.py:854-868) through the C ABI against oracle_chunk_stats (bit-exact), and
 ShadowKVCache_CPU.prefill_kv_cache built on the GPU (native pass) against the same cache built on the CPU with the
 reference-pinned torch ops."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -116,3 +118,59 @@ def test_prefill_state_built_on_gpu_equals_cpu_build(case):
         want_k = k_roped[0, h].view(-1, C, D)[ids].reshape(-1, D)
         assert_bits_equal(b.v_cache_buffer[0][0, h, ss:se].cpu(), want_v)
         assert_bits_equal(b.k_cache_buffer[0][0, h, ss:se].cpu(), want_k)
+
+
+def _recon(U, SV):
+    return torch.einsum("blr,bhdr->bhld", U.float(), SV.float())
+
+
+@pytest.mark.parametrize("case", ["llama_small", "glm_small"])
+def test_gram_factorisation_on_gpu_against_reference_pinned_factors(case):
+    """svd_mode='gram' on the GPU (K^T K -> eigh -> K V_r / s_r: SURVEY.md section 8f rank 2, replaces torch.svd at
+    /root/reference/models/kv_cache.py:700-733).  Column signs / algorithm differ from an SVD, so what decode consumes is
+    compared: the rank-160 reconstruction U.SV from the stored bf16 factors against the reconstruction from the factors the
+    REFERENCE produced (fixture svd_U / svd_SV, made by tests/golden/make_golden.py), rtol 1e-2 of the RMS key value."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{case}.npz"))
+    c, inp = G.CASES[case], G.make_inputs(case)
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=DEV, dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], svd_mode="gram")
+    cache.get_svd(inp["k_pre"].to(DEV), 0)
+    torch.cuda.synchronize()
+    bf = lambda a: torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16)
+    ref = torch.einsum("blr,bhrd->bhld", bf(z["svd_U"]).float(), bf(z["svd_SV"]).float())     # fixture SV is [1, kv, r, D]
+    got = _recon(cache.U[0], cache.SV[0]).cpu()
+    k = inp["k_pre"].float()
+    scale = k.pow(2).mean().sqrt()
+    assert float((got - ref).pow(2).mean().sqrt() / scale) < 1e-2
+    assert float((got - k).pow(2).mean().sqrt()) <= float((ref - k).pow(2).mean().sqrt()) * 1.02 + 1e-3 * float(scale)
+
+
+def test_gram_factorisation_at_headline_length_and_rank_deficient_keys():
+    """One layer at the headline length (L = 124,928 tokens, 8 KV heads x 128): Gram factorisation against torch.svd on
+    the same keys - the reconstructions agree to 1e-2 of the RMS key value and approximate K equally well; keys of rank
+    100 < 160 (48+ singular values at rounding-noise level) must give finite factors and the same reconstruction."""
+    from shadowkv_amd.kv_cache import gram_factorize
+    g = torch.Generator(device=DEV).manual_seed(3)
+    L, H, r = 122 * 1024, 1024, 160
+    a = torch.randn(1, L, r, device=DEV, generator=g)
+    b = torch.randn(1, r, H, device=DEV, generator=g) * (torch.arange(r, device=DEV).float().mul(-0.02).exp().view(1, r, 1))
+    k = (a @ b + 0.02 * torch.randn(1, L, H, device=DEV, generator=g)).bfloat16().float()
+    u_g, sv_g = gram_factorize(k, r)
+    u, s, v = torch.svd(k)
+    rec_svd = (u[:, :, :r].bfloat16().float() * 1) @ (torch.diag_embed(s[:, :r]) @ v.transpose(1, 2)[:, :r]).bfloat16().float()
+    rec_gram = u_g.bfloat16().float() @ sv_g.bfloat16().float()
+    scale = k.pow(2).mean().sqrt()
+    assert float((rec_gram - rec_svd).pow(2).mean().sqrt() / scale) < 1e-2
+    e_s, e_g = (rec_svd - k).pow(2).mean().sqrt(), (rec_gram - k).pow(2).mean().sqrt()
+    assert float(e_g) <= float(e_s) * 1.02 + 1e-3 * float(scale)
+    del u, s, v, rec_svd, rec_gram
+    k2 = (a[:, :20000, :100] @ b[:, :100]).bfloat16().float()          # rank 100 (+ bf16 rounding noise)
+    u2, sv2 = gram_factorize(k2, r)
+    assert bool(torch.isfinite(u2).all()) and bool(torch.isfinite(sv2).all())
+    assert float(u2.abs().max()) < 1e3                                   # no noise / ~0 columns
+    rec2 = u2.bfloat16().float() @ sv2.bfloat16().float()
+    assert float((rec2 - k2).pow(2).mean().sqrt() / k2.pow(2).mean().sqrt()) < 2e-2
+    k3 = torch.zeros(1, 4096, H, device=DEV)                             # all-zero keys: zero factors, not NaN
+    u3, sv3 = gram_factorize(k3, r)
+    assert float(u3.abs().max()) == 0.0 and float(sv3.abs().max()) == 0.0
