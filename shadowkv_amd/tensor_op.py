@@ -247,7 +247,9 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     if not q.is_contiguous():
         q = q.contiguous()
     if splits is None:
-        splits = max(1, min(32, 256 // max(1, bs * Hkv)))
+        # one workgroup per (kv head, split): fill the 256 CUs (profiles/r02_attn_mfma_probe.txt: 64 splits beat 32 for
+        # 4 KV heads); the combine kernel merges up to 62 records
+        splits = max(1, min(60, 256 // max(1, bs * Hkv)))
     ws = attention_workspace(q.device, bs, Hq, splits)
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
