@@ -424,18 +424,17 @@ class GraphDecoder:
 
     @staticmethod
     def _topk(x, k, parts=64):
-        """torch.topk(x, k, dim=-1).  For bs > 1 over a large vocabulary: two levels of short-slice top-k (top-k of
-        each of `parts` slices, then top-k of the parts*k survivors - the global top-k is a subset of them), because
-        PyTorch's multi-block top-k with more than one slice faults under hipGraph replay on this ROCm build
-        (tools/topk_graph_probe.py, pure PyTorch); short slices take its single-block path.  One slice (bs == 1)
-        replays fine and is the cheaper call there."""
+        """torch.topk(x, k, dim=-1) for rows the native sampler does not take (vocabulary > 131,072: GLM-4).  Large
+        rows always go through two levels of SHORT-slice top-k (top-k of each of `parts` slices, then top-k of the
+        parts * k survivors - the global top-k is a subset of them): PyTorch's multi-block top-k over long slices faulted
+        under hipGraph replay on this ROCm build (round 1: bs > 1 over 128,256 logits), short slices take its single-block
+        path.  The row is padded with -inf to a multiple of `parts`, so no shape falls back to a long-slice call."""
         bs, V = x.shape
-        if bs == 1 or V < 16384:                 # one slice (multi-block path, fine under replay) / short slices
+        if V < 16384 or V // parts < k:          # short rows: single-block path as they are
             return torch.topk(x, k, dim=-1)
-        if V % parts or V // parts < k:
-            rows = [torch.topk(x[b:b + 1], k, dim=-1) for b in range(bs)]     # one slice per call
-            return torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
-        w = V // parts
+        w = (V + parts - 1) // parts
+        if w * parts != V:
+            x = torch.nn.functional.pad(x, (0, w * parts - V), value=float("-inf"))
         v1, i1 = torch.topk(x.view(bs, parts, w), k, dim=-1)                   # [bs, parts, k]
         i1 = i1 + (torch.arange(parts, device=x.device) * w).view(1, parts, 1)
         v2, i2 = torch.topk(v1.reshape(bs, parts * k), k, dim=-1)
