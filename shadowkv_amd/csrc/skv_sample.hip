@@ -86,6 +86,7 @@ __device__ __forceinline__ float key_to_float(int key) {
     return __uint_as_float(x << 16);
 }
 
+#define SMP_CAND (2 * T2_THREADS)    // candidates the exact search takes (two per thread)
 template <int SEGV>
 __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     const bf16_t* __restrict__ logits, long long row_stride, int V, int k, float inv_temp, float top_p,
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
     int* s_out = s_w + 80;                            // [16]
     int* s_cur = s_out + 16;                          // [64] token id per selected position (ascending id)
-    float* s_sv = reinterpret_cast<float*>(s_cur + 64);   // [64] sorted: logit / temperature, descending
+    int* s_cidx = s_cur + 64;                         // [SMP_CAND] token ids of the prefilter's candidates, ascending
+    float* s_sv = reinterpret_cast<float*>(s_cidx + SMP_CAND);   // [64] sorted: logit / temperature, descending
     int* s_si = reinterpret_cast<int*>(s_sv + 64);    // [64] sorted: token id
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     constexpr int NW = 4 * SEGV, NG = (NW + 15) / 16;
@@ -120,6 +122,70 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
 #pragma unroll
         for (int q = 0; q < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++q) hz[tid + q * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
     }
+    // ---- prefilter: the k-th largest of the 1,024 per-thread maxima is a lower bound L of the k-th largest logit (k
+    // distinct logits are >= L), so only logits >= L can be winners: a few dozen of 128 K.  They are compacted (token
+    // order) and the exact search runs on them: one histogram atomic per thread instead of 8 * SEGV * ... per thread.
+    bool done = false;
+    {
+        uint32_t m2 = w[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) m2 = pk_max_u16(m2, w[i]);
+        const uint32_t w1[1] = {max(m2 & 0xffffu, m2 >> 16)};               // (high half: padding key 0)
+        int thr_l, ne_l;
+        t2_find_threshold<1>(w1, T2_THREADS, k, tid, s_hist, s_w, s_out, thr_l, ne_l, [] {});
+        uint32_t mc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) mc[g] = 0u;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int lo = (int)(w[i] & 0xffffu), hi = (int)(w[i] >> 16);
+            mc[i / 16] |= ((uint32_t)(lo >= thr_l) | ((uint32_t)(hi >= thr_l) << 1)) << (2 * (i % 16));
+        }
+        int cc = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) cc += __builtin_popcount(mc[g]);
+        const int cincl = block_scan_incl1(cc, s_w + 32, tid);
+        if (tid == T2_THREADS - 1) s_out[8] = cincl;
+        {   // the histogram is searched again below (either path)
+            u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+            for (int q = 0; q < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++q) hz[tid + q * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        int o = cincl - cc;
+        if (cincl <= SMP_CAND) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                uint32_t m = mc[g];
+                while (m) {
+                    s_cidx[o++] = j0 + g * 32 + __builtin_ctz(m);
+                    m &= m - 1;
+                }
+            }
+        }
+        __syncthreads();
+        const int C = s_out[8];
+        if (C <= SMP_CAND) {                                              // (always, unless thousands of logits tie)
+            const int c0 = 2 * tid, c1 = 2 * tid + 1;
+            const int id0 = c0 < C ? s_cidx[c0] : -1, id1 = c1 < C ? s_cidx[c1] : -1;
+            const bf16_t* row = logits + (size_t)b * row_stride;
+            const uint32_t k0 = bf16x2_to_keys((uint32_t)row[max(id0, 0)]) & 0xffffu, k1 = bf16x2_to_keys((uint32_t)row[max(id1, 0)]) & 0xffffu;
+            const uint32_t w2[1] = {(id0 >= 0 ? k0 : 0u) | ((id1 >= 0 ? k1 : 0u) << 16)};
+            int thr, need_eq;
+            t2_find_threshold<1>(w2, 2 * T2_THREADS - C, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+            const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
+            const bool v0 = id0 >= 0, v1 = id1 >= 0;
+            const int g0 = v0 && lo > thr, g1 = v1 && hi > thr, e0 = v0 && lo == thr, e1 = v1 && hi == thr;
+            const int packed = (g0 + g1) | (min(e0 + e1, need_eq) << 10);
+            const int pexcl = block_scan_incl1(packed, s_w + 48, tid) - packed;
+            int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+            if (g0) s_cur[gt_run++ + min(eq_run, need_eq)] = id0;
+            else if (e0) { if (eq_run < need_eq) s_cur[gt_run + eq_run] = id0; ++eq_run; }
+            if (g1) s_cur[gt_run + min(eq_run, need_eq)] = id1;
+            else if (e1 && eq_run < need_eq) s_cur[gt_run + eq_run] = id1;
+            done = true;
+        }
+    }
+    if (!done) {
     int thr, need_eq;
     t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - V, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
     // flags (keys use all 16 bits here: plain compares), ordered compaction as in skv_topk2_kernel
@@ -144,7 +210,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     }
     ce = min(ce - cg, need_eq);
     const int packed = cg | (ce << 10);
-    const int pexcl = block_scan_incl1(packed, s_w + 32, tid) - packed;
+    const int pexcl = block_scan_incl1(packed, s_w + 48, tid) - packed;
     {
         int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
 #pragma unroll
@@ -164,6 +230,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
                 if (p >= 0) s_cur[p] = j0 + g * 32 + e;
             }
         }
+    }
     }
     __syncthreads();
     // ---- sort the k winners by (value descending, token id ascending): rank by counting, one lane per winner
@@ -231,7 +298,7 @@ static int launch_sample_topk(const void* logits, long long row_stride, int V, i
                               unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
                               int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
                               const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, hipStream_t st) {
-    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3) * sizeof(int);
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3 + SMP_CAND) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)skv_sample_topk_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
