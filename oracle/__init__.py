@@ -58,6 +58,10 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(_i(int(n)))
+
+
 def group_max_topk(P, landmark_idx, blocks, groups, n, topk):
     """P bf16 [blocks, groups, n] -> int64 [blocks, topk] (ascending slot order)."""
     out = torch.empty(blocks, topk, dtype=torch.int64)

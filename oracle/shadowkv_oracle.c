@@ -446,6 +446,7 @@ ORACLE_API void oracle_batch_gather_gemm(const uint16_t *U, const uint16_t *SV,
 
 /* threads the parallel loops above run on (bench.py reports it with the cpu_baseline) */
 ORACLE_API int oracle_num_threads(void) { return omp_get_max_threads(); }
+ORACLE_API void oracle_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 /* ------------------------------------------------------------------------- */
 /* a8: RoPE and push into the key cache (kernels/rope_new.cu)                */

@@ -9,7 +9,7 @@
 #define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
 #define AT_REC 132     // floats per (head, split) record: acc[128], m, l, 2 pad (16-B aligned rows)
 
-template <int G, bool MASKED>
+template <int G, bool MASKED, int AT_KB = 4 /* keys per 16-lane group and iteration: 2 * AT_KB row loads in flight */>
 __device__ __forceinline__ void skv_attn_partial_body(
     const bf16_t* __restrict__ q,   // [bs][Hq][128]
     const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
@@ -57,7 +57,6 @@ __device__ __forceinline__ void skv_attn_partial_body(
     const bf16_t* vb = v + (size_t)bh * kv_stride_h + 8 * sub;
     // A 16-lane group takes AT_KB keys per iteration (keys grp + 16*i): 2*AT_KB row loads in flight, the scores of
     // the batch are reduced first, then ONE running-max update / accumulator rescale per batch instead of per key.
-    constexpr int AT_KB = 4;
     for (int key0 = k0 + grp; key0 < k1; key0 += AT_GROUPS * AT_KB) {
         u32x4 kr[AT_KB], vr[AT_KB];
         bool alive[AT_KB];

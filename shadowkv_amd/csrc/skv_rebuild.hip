@@ -190,7 +190,7 @@ __device__ __forceinline__ void skv_tile_merge(const float* s_part_raw, float* _
 }
 
 template <int MODE /*0 = pre-RoPE output, 1 = Llama RoPE, 2 = GLM RoPE*/, int KS, int AG = 0 /* attention role: G */>
-__global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
+__global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuild_kernel(
     const bf16_t* __restrict__ U,        // [bs][seq_len][R]
     const bf16_t* __restrict__ SV,       // [bs][heads][128][R]
     const bf16_t* __restrict__ cos_sin,  // [max_pos][cs_stride]
@@ -210,19 +210,26 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
     // the remaining CUs and are PCIe-bound.
     int rebuild_tiles, const u32x4* __restrict__ v_host, u32x4* __restrict__ v_buf, const u32x4* __restrict__ v_temp,
     long long v_host_stride_u128, long long v_stride_u128, long long v_off_u128, int land_blocks, AttnRole ar) {
-    // block -> (role index bx, batch*head by).  Attention role present: a 1-D grid, the tiles of ALL heads first and from
-    // the highest tile index down (the live tiles - miss chunks - are the last ones and are the long pole: their host
-    // loads should go out at once), then the split-attention workgroups over the resident rows.
+    // block -> (role index bx, batch*head by).  Attention role present: a 1-D grid in which the tile blocks (from the
+    // highest tile index down, all heads of a tile index together: the live tiles - miss chunks - are the last indices
+    // and are the long pole, their host loads should go out at once) are INTERLEAVED with the split-attention blocks over
+    // the resident rows in the ratio of their counts.  One 512-thread workgroup fits per CU, blocks get CUs in id order:
+    // with all tiles first, a batch with more live tiles than CUs (bs >= 3 at 67 % hits) would start the attention blocks
+    // only after the PCIe-bound tiles had drained and lose the overlap.
     int bx = blockIdx.x, by = blockIdx.y;
     if constexpr (AG > 0) {
-        const int nbh = (int)gridDim.x / (rebuild_tiles + ar.splits);
-        if (bx < nbh * rebuild_tiles) {
-            by = bx % nbh;
-            bx = rebuild_tiles - 1 - bx / nbh;
+        const int per_head = rebuild_tiles + ar.splits;
+        const int nbh = (int)gridDim.x / per_head;
+        const long long na = (long long)nbh * ar.splits, nall = (long long)gridDim.x;
+        const int a_before = (int)((long long)bx * na / nall);                   // attention blocks with a smaller id
+        const bool is_attn = (int)(((long long)bx + 1) * na / nall) > a_before;
+        if (!is_attn) {
+            const int t = bx - a_before;                                          // tile blocks with a smaller id
+            by = t % nbh;
+            bx = rebuild_tiles - 1 - t / nbh;
         } else {
-            const int r = bx - nbh * rebuild_tiles;
-            by = r % nbh;
-            bx = rebuild_tiles + r / nbh;
+            by = a_before % nbh;
+            bx = rebuild_tiles + a_before / nbh;
         }
     }
     if constexpr (AG > 0) if (bx >= rebuild_tiles + land_blocks) {
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
         const int bh3 = by, cnt3 = cnts ? cnts[bh3] : 0;
         const int kv_len = min(ar.kv_len_dev ? *ar.kv_len_dev : ar.kv_len_host, ar.kv_rows);
-        skv_attn_partial_body<AG, true>(
+        skv_attn_partial_body<AG, true, (AG == 8 ? 1 : 2)>(
             ar.q, out, reinterpret_cast<const bf16_t*>(v_buf), ar.ws, kv_len, out_stride_h, ar.splits, ar.rec_splits,
             bx - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
             dst_slots + (size_t)bh3 * S + cnt3, S - cnt3, out_row0, S * C);
@@ -383,15 +390,15 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
     u32x4 afrag[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) afrag[ks] = *reinterpret_cast<const u32x4*>(urow + 32 * ks);
-    // SV[b][h] -> registers (stored to LDS below)
-    u32x4 svreg[SV_ITERS];
-    {
-        const u32x4* src = reinterpret_cast<const u32x4*>(SV + (size_t)bh * RB_D * R);
+    // SV[b][h] -> registers (stored to LDS below); with the attention role the staging goes in two halves to keep the
+    // kernel at 128 VGPRs (two 512-thread workgroups per CU: while one waits on PCIe the other's loads are in flight)
+    constexpr int SV_HALF = AG > 0 ? (SV_ITERS + 1) / 2 : SV_ITERS;
+    u32x4 svreg[SV_HALF];
+    const u32x4* const sv_src = reinterpret_cast<const u32x4*>(SV + (size_t)bh * RB_D * R);
 #pragma unroll
-        for (int it = 0; it < SV_ITERS; ++it) {
-            const int u = tid + it * 256;
-            if (u < RB_D * UNITS_PER_ROW) svreg[it] = src[u];
-        }
+    for (int it = 0; it < SV_HALF; ++it) {
+        const int u = tid + it * 256;
+        if (u < RB_D * UNITS_PER_ROW) svreg[it] = sv_src[u];
     }
     // cos / sin of the rows this thread will finish in the epilogue
     u32x4 ecos[MODE == 0 ? 1 : EPI_ITERS], esin[MODE == 0 ? 1 : EPI_ITERS];
@@ -424,11 +431,21 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256) void skv_rebuild_kernel(
     }
     // ---- phase 2: SV -> LDS (rows padded to 336 B: conflict-free 16-row x 16-B fragment reads)
 #pragma unroll
-    for (int it = 0; it < SV_ITERS; ++it) {
-        const int u = tid + it * 256;
-        if (u < RB_D * UNITS_PER_ROW) {
-            const int row = u / UNITS_PER_ROW, c16 = u % UNITS_PER_ROW;
-            *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = svreg[it];
+    for (int half = 0; half * SV_HALF < SV_ITERS; ++half) {
+        if (half > 0) {
+#pragma unroll
+            for (int it = 0; it < SV_HALF; ++it) {
+                const int u = tid + (half * SV_HALF + it) * 256;
+                if (half * SV_HALF + it < SV_ITERS && u < RB_D * UNITS_PER_ROW) svreg[it] = sv_src[u];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < SV_HALF; ++it) {
+            const int u = tid + (half * SV_HALF + it) * 256;
+            if (half * SV_HALF + it < SV_ITERS && u < RB_D * UNITS_PER_ROW) {
+                const int row = u / UNITS_PER_ROW, c16 = u % UNITS_PER_ROW;
+                *reinterpret_cast<u32x4*>(sSV + row * RB_SV_PITCH + c16 * 16) = svreg[it];
+            }
         }
     }
     if constexpr (AG > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see barrier (1) of the attention waves
@@ -556,6 +573,10 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                    (part <= (size_t)RB_D * RB_SV_PITCH ? 0 : part);
         const size_t need = part + 32 * sizeof(uint32_t);     // resident-rows role
         if (need > smem_all) smem_all = need;
+        // ONE workgroup per CU (LDS request above half of the 160 KB): measured with in-kernel stamps and A/B runs, a CU
+        // with host-memory loads outstanding serves its other memory traffic only when they return, so a second workgroup
+        // sharing the CU (rebuild or attention role) stalls behind the first one's PCIe round trip (bs 1: 38.1 vs 36.4 us)
+        if (smem_all < 84 * 1024) smem_all = 84 * 1024;
     }
     dim3 grid(tiles + land_blocks, bs * heads), block(256);
     if (attn) {

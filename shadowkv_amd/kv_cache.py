@@ -476,9 +476,19 @@ class ShadowKVCache_CPU:
 
     OVERLAP_SPLITS = 24   # split pass over the resident rows inside the fetch launch (+ one record per miss tile)
 
+    def _overlap_splits(self):
+        """~192 split-attention workgroups next to the tile workgroups whatever the batch (24 per head at bs 1, never
+        fewer than 4): more would only queue behind the PCIe-bound tiles on the 256 CUs."""
+        return max(4, min(self.OVERLAP_SPLITS, -(-192 // self.block_num)))
+
     def can_overlap_attention(self):
+        # one sequence per GPU (<= 8 (batch, head) blocks): the fused launch hides the attention behind the PCIe fetch.
+        # Batches are PCIe-bound outright and keep the link busier with the plain fetch launch (separate landing
+        # workgroups, two per CU) + the standalone attention: measured 296 / 451 / 596 / 739 tok/s at bs 2 / 4 / 8 / 24
+        # against 292 / 427 / 562 / 687 with the fused launch
         return (self.rank == 160 and self.chunk_size == 8 and self.head_dim == 128 and self.select_sets % 8 == 0
-                and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 64)
+                and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 64
+                and self.block_num <= 8)
 
     def select_fetch_attend_inplace(self, layer_idx, query_states, cos_sin_cache, kv_len=0, kv_len_dev=None):
         """select_fetch_inplace + sparse attention of one layer with the attention over the already-resident rows
@@ -502,7 +512,7 @@ class ShadowKVCache_CPU:
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
         L, st = lib(), current_stream_handle()
         bs, Hq, D = q.shape[0], self.num_attention_heads, self.head_dim
-        SA = self.OVERLAP_SPLITS
+        SA = self._overlap_splits()
         ws = tensor_op.attention_workspace(q.device, bs, Hq, SA + self.select_sets // 8)
         check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
                                           ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
