@@ -1,5 +1,6 @@
 // Diagnostic build of the top-k + diff kernel with phase stamps (see TOPK_STAMP in skv_select.hip).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSKV_TOPK_STAMPS -I shadowkv_amd/csrc tools/topk_probe.hip -o /tmp/topk_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DSKV_TOPK_STAMPS] -I shadowkv_amd/csrc tools/topk_probe.hip -o /tmp/topk_probe
+// (without the define: the shipped kernel, event-timed back to back only)
 #include "../shadowkv_amd/csrc/skv_select.hip"
 #include <stdio.h>
 #include <math.h>
@@ -22,6 +23,17 @@ int main(int argc, char** argv) {
             p = 6.4e-5f * expf(sigma * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2));
         }
         uint32_t u; memcpy(&u, &p, 4); v = u >> 16;
+    }
+    if (argc > 5) {   // argv[5] = run length: the top scores sit in runs of that many consecutive landmark slots (attention locality)
+        const int runlen = atoi(argv[5]), nruns = (S + runlen - 1) / runlen;
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < nruns; ++r) {
+                const int start = (int)((size_t)rand() % (N - runlen));
+                for (int j = start; j < start + runlen; ++j) {
+                    float p = 1e-3f * (1.0f + 0.5f * rand() / RAND_MAX);
+                    uint32_t u; memcpy(&u, &p, 4); sc[(size_t)b * stride + j] = u >> 16;
+                }
+            }
     }
     for (int b = 0; b < B; ++b) for (int j = 0; j < N; ++j) lm[(size_t)b * N + j] = j + j / 300;
     for (int b = 0; b < B; ++b) for (int j = 0; j < S; ++j) cached[(size_t)b * S + j] = (j * 61) % N;
@@ -48,6 +60,7 @@ int main(int argc, char** argv) {
         }
         int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
         hipDeviceSynchronize();
+#ifdef SKV_TOPK_STAMPS
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
 #ifdef SKV_TOPK_V1
         const char* names[] = {"stage+hist1(+hash build)", "select1+zero", "hist2", "select2", "count", "scan", "assign+gather", "-", "lookup", "scan2", "sorted-vote", "write"};
@@ -59,6 +72,9 @@ int main(int argc, char** argv) {
         printf("run %d rc=%d total %.2f us :", it, rc, (st[ns] - st[0]) / 100.0);
         for (int i = 0; i < ns; ++i) printf(" %s=%.2f", names[i], (st[i + 1] - st[i]) / 100.0);
         printf("\n");
+#else
+        (void)rc;
+#endif
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
