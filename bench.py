@@ -83,7 +83,7 @@ def cpu_model_name():
 # ----------------------------------------------------------------------------------------------------------------------
 # model / state
 # ----------------------------------------------------------------------------------------------------------------------
-def build_model(workload, args, rank, dev, layout=None, overlap=None):
+def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_sets=None):
     from shadowkv_amd import llama
     cfg_name, ctx, budget = WORKLOADS[workload]
     cfg = getattr(llama, cfg_name)
@@ -94,7 +94,8 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None):
                             attn_mode="full" if full else "shadowkv_cpu",
                             chunk_layout=layout or args.layout, v_offload=args.v_table == "host",
                             overlap_attention=bool(args.overlap_attention if overlap is None else overlap),
-                            max_new_tokens=max(1024, 4 * (args.warmup + args.steps) + 256))
+                            max_new_tokens=max(1024, 4 * (args.warmup + args.steps) + 256),
+                            resident_sets=resident_sets if resident_sets is not None else args.resident_sets)
     if full:
         llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
     else:
@@ -117,6 +118,8 @@ def pinned_eviction(model, pin):
     the selected chunks are found resident.  One strided copy per step, captured with it."""
     c = model.kv_cache
     S = c.select_sets
+    if c.resident_sets != S:
+        raise ValueError("--pin-hit-rate pins the hit rate of the reference's resident set (resident_sets == select_sets)")
     n_evict = S - int(round(pin * S))
     if n_evict == 0:
         return None
@@ -422,6 +425,10 @@ def main():
     ap.add_argument("--walk-step", type=float, default=0.3)
     ap.add_argument("--pin-hit-rate", type=float, default=None,
                     help="constant query + forced evictions: exactly this fraction of the selected chunks is resident")
+    ap.add_argument("--resident-sets", type=int, default=None,
+                    help="chunk slots kept resident per head (default: select_sets = budget / 8, the reference's resident "
+                         "set; larger: a selected chunk found in any slot is a hit, least recently selected slots are "
+                         "replaced - same outputs, fewer chunks over PCIe; in-place layout only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
@@ -468,14 +475,15 @@ def main():
                           path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                           pcie_gbs_in_path=round(pcie_gbs, 2), pcie_frac_of_spec=round(pcie_gbs / PCIE_PEAK_GBS, 3))
             short = dict(steps=24, warmup=4)
-            if args.pin_hit_rate is None and args.mode == "graph" and args.query_mode == "walk":
+            ref_set = cache.resident_sets == cache.select_sets
+            if args.pin_hit_rate is None and args.mode == "graph" and args.query_mode == "walk" and ref_set:
                 sweep = []
                 for pin in (0.0, 0.6):            # the pinned extremes next to the walk's measured rate
                     r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=7, pin_hit=pin)
                     sweep.append(dict(pinned_hit_rate=pin, measured_hit_rate=round(r["hit_rate"], 4),
                                       value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]))
                 extras["hit_rate_sweep"] = sweep
-            if args.layout == "inplace":          # the reference's slot order (hits compacted to the front), no overlap
+            if args.layout == "inplace" and ref_set:   # the reference's slot order (hits compacted to the front), no overlap
                 # (same state: "slot i holds chunk position_ids[i]" is the invariant of both layouts)
                 model.chunk_layout, model.overlap_attention = "reference", False
                 r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
@@ -497,7 +505,7 @@ def main():
             "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
-                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
+                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}{'' if full or cache.resident_sets == cache.select_sets else f', {cache.resident_sets} resident chunk slots per head (LRU; NOT the reference resident set)'}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
                                    + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)")
                                    + ("" if args.pin_hit_rate is None else f" (chunk hit rate pinned to {args.pin_hit_rate})"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
@@ -530,6 +538,18 @@ def main():
                                 value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1)))
             out["secondary"] = sec
+            # the same workload with 512 resident chunk slots per head (HBM is plentiful, the link is the roof): identical
+            # selections and outputs, fewer chunks over PCIe.  Not the headline: the reference's resident set is the last
+            # selection (256 slots).
+            if args.resident_sets is None and args.layout == "inplace" and args.mode == "graph":
+                model = cache = None
+                gc.collect(); torch.cuda.empty_cache()
+                model, _, ctx3, _, tb = build_model(args.workload, args, rank, dev, resident_sets=512)
+                r = run_decode(model, args, ctx3, 32, 12, args.walk_step, seed=99 + rank)
+                out["value_resident_512"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=32, warmup=12,
+                                                 note="--resident-sets 512: least-recently-selected replacement over 512 "
+                                                      "slots per head, attention over the 256 selected chunks as before")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -159,10 +159,11 @@ SKV_EXPORT int skv_select_chunks(const void* q, const void* landmarks, const int
  * scores (non-negative: softmax probabilities after the group max; ties at the k-th value -> lowest landmark slot),
  * slot -> chunk id, diff against the resident set.  scores [blocks][score_stride] bf16, score_stride % 8 == 0 and
  * >= n_landmarks, rows 16-B aligned.  dst_slots NULL: reference slot order (offsets = old slot / chunk id as in
- * skv_select_chunks); non-NULL: in-place layout (offsets = miss ids, as in skv_select_chunks_inplace). */
+ * skv_select_chunks); non-NULL: in-place layout (offsets = miss ids, as in skv_select_chunks_inplace, which also
+ * explains resident_sets / slot_age; reference slot order: resident_sets == select_sets, slot_age NULL). */
 SKV_EXPORT int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,
                            int32_t* offsets, int32_t* dst_slots, int32_t* cnts, int64_t* selected_out, int blocks,
-                           int n_landmarks, int select_sets, skv_stream_t stream);
+                           int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, skv_stream_t stream);
 
 /* Stage 1 of skv_select_chunks alone (the HBM-bound landmark scan), for roofline measurement and
  * profiling: logits bf16 [blocks][groups][n] and per-256-landmark partial (max, sum) f32
@@ -218,6 +219,14 @@ SKV_EXPORT size_t skv_attn_workspace_bytes(int batch_size, int q_heads, int spli
 SKV_EXPORT int skv_sparse_attention(const void* q, const void* k, const void* v, void* out, void* workspace,
                          const int32_t* kv_len_dev, int kv_len, int kv_rows, long long kv_head_stride, int batch_size,
                          int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream);
+
+/* skv_sparse_attention over a resident set larger than the selection: of the sparse region [sparse_start, sparse_start +
+ * resident_sets * 8) only the chunks in slots[b * kv_heads + h][0 .. select_sets) are attended (the array
+ * skv_select_chunks_inplace leaves in dst_slots), rows before and behind the region as usual. */
+SKV_EXPORT int skv_sparse_attention_slots(const void* q, const void* k, const void* v, void* out, void* workspace,
+                               const int32_t* kv_len_dev, int kv_len, int kv_rows, long long kv_head_stride, int batch_size,
+                               int q_heads, int kv_heads, int head_dim, int splits, float scale, const int32_t* slots,
+                               int select_sets, int sparse_start, int resident_sets, skv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Part 3: small fused host-model ops of the decode step (what sits between the dense projections and
@@ -281,12 +290,21 @@ SKV_EXPORT int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const v
  * /root/reference/models/kv_cache.py:1006-1057 (and the same `selected_out`), a different slot ORDER: no resident row
  * ever moves, so the d2d compaction of reorder_keys_and_compute_offsets + gather_copy_d2d_with_offsets
  * (/root/reference/kernels/map.cuh:754-796, gather_copy.cu) has nothing to do.  Attention is order-independent.
- *   cached_pos_ids [blocks][S] in/out: id per slot (only the freed slots are rewritten)
- *   cnts [blocks] out: hits;   for r in [0, S - cnt): miss_ids[b][cnt + r] = id, dst_slots[b][cnt + r] = slot */
+ *   cached_pos_ids [blocks][R] in/out: id per slot (only the freed slots are rewritten; negative = empty slot)
+ *   cnts [blocks] out: hits;   for r in [0, S - cnt): miss_ids[b][cnt + r] = id, dst_slots[b][cnt + r] = slot
+ *   dst_slots[b][0 .. cnt) = the slots of the hits, ascending (so dst_slots[b][0 .. S) lists the S attended slots)
+ * Resident set larger than the selection (MI355X: HBM is plentiful, the PCIe link is the roof): R = resident_sets >=
+ * S = select_sets slots per head (R <= 1024).  A selected chunk found in ANY of the R slots is a hit; the S - cnt misses
+ * replace the least recently selected of the slots that were not selected in this step (slot_age int32 [blocks][R]
+ * in/out: steps since the slot's chunk was last selected, saturating at 62; 63 = empty slot, taken first; ties ->
+ * lowest slot).  Attention still runs over exactly the S selected chunks (skv_fetch_kv_attn_inplace,
+ * skv_sparse_attention_slots): same outputs, fewer chunks over PCIe.  R == S: the policy above degenerates to "every
+ * slot not selected again is replaced" - the reference's resident set; slot_age may be NULL. */
 SKV_EXPORT int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_t* landmark_idx,
                               int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
                               void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
-                              int n_landmarks, int select_sets, float alpha, skv_stream_t stream);
+                              int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
+                              skv_stream_t stream);
 
 /* skv_fetch_kv for the in-place layout: K rows of the misses rebuilt (U[idx].SV^T + RoPE) and V chunks of the misses
  * fetched from the pinned host table, each written to slot dst_slots[.] of the sparse region; one launch. */
@@ -298,7 +316,8 @@ SKV_EXPORT int skv_fetch_kv_inplace(const void* U, const void* SV, const void* c
                          skv_stream_t stream);
 
 /* skv_fetch_kv_inplace plus the attention, in the same launch: (1) extra workgroups run the split attention pass over
- * every row that is NOT a miss slot - those rows are final before the launch starts, so they ride on the CUs the
+ * the rows that are final before the launch starts (local, outliers, the chunks selected again - dst_slots[.][0 .. cnt)
+ * -, generated tokens, which sit behind the resident_sets * 8 rows of the sparse region), so they ride on the CUs the
  * PCIe-bound V fetch leaves idle; (2) every workgroup that builds a miss tile (8 chunks: K rebuilt, V fetched by the same
  * workgroup, host loads issued first) attends its 64 rows from LDS before it exits.  Records go to attn_workspace:
  * skv_attn_workspace_bytes(bs, q_heads, attn_splits + select_sets / 8).  Follow with skv_attn_finish_inplace.  Together
@@ -311,7 +330,7 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
                               int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
                               int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
-                              int attn_splits, float scale, skv_stream_t stream);
+                              int attn_splits, int resident_sets, float scale, skv_stream_t stream);
 
 /* Merge of the records skv_fetch_kv_attn_inplace left (resident splits + live miss tiles, told by cnts);
  * out [bs][q_heads][128] bf16. */

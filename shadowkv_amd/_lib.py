@@ -37,12 +37,12 @@ _SIGS = {
     "skv_apply_rotary_pos_emb": (c_int, [c_p] * 5 + [c_int] * 14 + [c_p]),
     "skv_select_workspace_bytes": (c_sz, [c_int] * 3),
     "skv_select_chunks": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f, c_p]),
-    "skv_select_chunks_inplace": (c_int, [c_p] * 10 + [c_int] * 4 + [c_f, c_p]),
+    "skv_select_chunks_inplace": (c_int, [c_p] * 10 + [c_int] * 5 + [c_p, c_f, c_p]),
     "skv_fetch_kv_inplace": (c_int, [c_p] * 9 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
-    "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 10 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_f, c_p]),
+    "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 10 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_int, c_f, c_p]),
     "skv_attn_finish_inplace": (c_int, [c_p] * 3 + [c_int] * 5 + [c_p]),
     "skv_sample_advance": (c_int, [c_p] * 2 + [c_int] * 2 + [c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
-    "skv_select_from_scores": (c_int, [c_p, c_int] + [c_p] * 6 + [c_int] * 3 + [c_p]),
+    "skv_select_from_scores": (c_int, [c_p, c_int] + [c_p] * 6 + [c_int] * 4 + [c_p, c_p]),
     "skv_sample_topk_advance": (c_int, [c_p, c_ll] + [c_int] * 3 + [c_f, c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
     "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
@@ -59,6 +59,7 @@ _SIGS = {
     "skv_chunk_stats": (c_int, [c_p, c_ll] + [c_int] * 4 + [c_p] * 3),
     "skv_linear_rows_bf16": (c_int, [c_p] * 4 + [c_int] * 4 + [c_p]),
     "skv_sparse_attention": (c_int, [c_p] * 6 + [c_int, c_int, c_ll] + [c_int] * 5 + [c_f, c_p]),
+    "skv_sparse_attention_slots": (c_int, [c_p] * 6 + [c_int, c_int, c_ll] + [c_int] * 5 + [c_f, c_p] + [c_int] * 3 + [c_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -17,6 +17,9 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st);
+int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
+                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
+                             int B, int N, int S, int R, int32_t* slot_age, hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, void* temp, const int32_t* offsets, const int32_t* cnts,
                          long long host_len_elems, long long dev_stride_elems, long long dev_off_elems, int B, int S,
                          hipStream_t st);
@@ -39,7 +42,8 @@ int skv_launch_land_rows(const void* host_rows, void* buf, const void* temp, con
                          int B, int S, hipStream_t st);
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
                                 const int* kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h, int bs, int Hq,
-                                int Hkv, int head_dim, int splits, float scale, hipStream_t st);
+                                int Hkv, int head_dim, int splits, float scale, const int32_t* slots, int n_slots,
+                                int sparse_start, int resident_rows, hipStream_t st);
 int skv_launch_rope_chunked(const void* x, const void* cos_sin, const int32_t* pid, void* out, const int32_t* cnts,
                             int batch, int heads, int seq_len, int embed_dim, long long sxb, long long sxh,
                             long long sxs, long long sxe, long long scs, long long spb, long long sph, long long sps,
@@ -255,9 +259,10 @@ int skv_select_chunks(const void* q, const void* landmarks, const int64_t* landm
 int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_t* landmark_idx,
                               int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
                               void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
-                              int n_landmarks, int select_sets, float alpha, skv_stream_t stream) {
+                              int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
+                              skv_stream_t stream) {
     if (!q || !landmarks || !cached_pos_ids || !miss_ids || !dst_slots || !cnts || !workspace) return SKV_ERR_ARG;
-    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1 || resident_sets < select_sets) return SKV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st);
@@ -265,17 +270,19 @@ int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_
     rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
                                        n_landmarks, st);
     if (rc != SKV_OK) return rc;
-    return finish(skv_launch_topk_reorder(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
-                                          selected_out, dst_slots, blocks, n_landmarks, select_sets, st));
+    return finish(skv_launch_topk_resident(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
+                                           selected_out, dst_slots, blocks, n_landmarks, select_sets, resident_sets,
+                                           slot_age, st));
 }
 
 int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,
                            int32_t* offsets, int32_t* dst_slots, int32_t* cnts, int64_t* selected_out, int blocks,
-                           int n_landmarks, int select_sets, skv_stream_t stream) {
+                           int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, skv_stream_t stream) {
     if (!scores || !cached_pos_ids || !offsets || !cnts) return SKV_ERR_ARG;
-    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
-    return finish(skv_launch_topk_reorder(scores, score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
-                                          selected_out, dst_slots, blocks, n_landmarks, select_sets, (hipStream_t)stream));
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1 || resident_sets < select_sets) return SKV_ERR_ARG;
+    return finish(skv_launch_topk_resident(scores, score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
+                                           selected_out, dst_slots, blocks, n_landmarks, select_sets, resident_sets,
+                                           slot_age, (hipStream_t)stream));
 }
 
 int skv_score_landmarks(const void* q, const void* landmarks, void* logits, float* part_max, float* part_sum,
@@ -336,14 +343,14 @@ int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin
                               int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
                               int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
-                              int attn_splits, float scale, skv_stream_t stream) {
+                              int attn_splits, int resident_sets, float scale, skv_stream_t stream) {
     if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache || !q ||
         !attn_workspace)
         return SKV_ERR_ARG;
     if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
     if (select_sets % 8) return SKV_ERR_UNSUPPORTED;
     AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits + select_sets / 8,
-                  scale};
+                  scale, resident_sets};
     return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
@@ -380,8 +387,18 @@ int skv_sparse_attention(const void* q, const void* k, const void* v, void* out,
                          int q_heads, int kv_heads, int head_dim, int splits, float scale, skv_stream_t stream) {
     if (!q || !k || !v || !out || !workspace) return SKV_ERR_ARG;
     return finish(skv_launch_sparse_attention(q, k, v, out, workspace, kv_len_dev, kv_len, kv_rows, kv_head_stride,
-                                              batch_size, q_heads, kv_heads, head_dim, splits, scale,
+                                              batch_size, q_heads, kv_heads, head_dim, splits, scale, nullptr, 0, 0, 0,
                                               (hipStream_t)stream));
+}
+
+int skv_sparse_attention_slots(const void* q, const void* k, const void* v, void* out, void* workspace,
+                               const int32_t* kv_len_dev, int kv_len, int kv_rows, long long kv_head_stride, int batch_size,
+                               int q_heads, int kv_heads, int head_dim, int splits, float scale, const int32_t* slots,
+                               int select_sets, int sparse_start, int resident_sets, skv_stream_t stream) {
+    if (!q || !k || !v || !out || !workspace || !slots || select_sets < 1 || resident_sets < select_sets) return SKV_ERR_ARG;
+    return finish(skv_launch_sparse_attention(q, k, v, out, workspace, kv_len_dev, kv_len, kv_rows, kv_head_stride,
+                                              batch_size, q_heads, kv_heads, head_dim, splits, scale, slots, select_sets,
+                                              sparse_start, resident_sets * 8, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -18,19 +18,23 @@
 #include "../../include/shadowkv_hip.h"
 #include "skv_attn_body.h"
 
-template <int G>
+template <int G, bool LISTED>
 __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     const bf16_t* __restrict__ q,   // [bs][Hq][128]
     const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
     const bf16_t* __restrict__ v,
     float* __restrict__ ws,         // [bs*Hkv][G][splits][AT_REC]  (acc[128], m, l)
     const int* __restrict__ kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h /*elements*/, int Hkv,
-    int splits, float scale) {
+    int splits, float scale,
+    // LISTED (resident set larger than the selection): of the region [sparse_start, + resident_rows) only the chunks in
+    // slots[bh][0 .. n_slots) are attended
+    const int32_t* __restrict__ slots, int n_slots, int sparse_start, int resident_rows) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     // never past the rows a head owns (the reference's view slice [:sparse_end + gen] clamps the same way)
     const int kv_len = min(kv_len_dev ? *kv_len_dev : kv_len_host, kv_rows);
-    skv_attn_partial_body<G, false>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
-                                    nullptr, 0, 0, 0);
+    skv_attn_partial_body<G, LISTED>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
+                                     LISTED ? slots + (size_t)blockIdx.y * n_slots : nullptr, n_slots, sparse_start,
+                                     resident_rows);
 }
 
 __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
@@ -123,24 +127,32 @@ extern "C" size_t skv_attn_workspace_bytes(int bs, int Hq, int splits) { return 
 
 int skv_launch_sparse_attention(const void* q, const void* k, const void* v, void* out, void* ws,
                                 const int* kv_len_dev, int kv_len_host, int kv_rows, long long kv_stride_h, int bs, int Hq,
-                                int Hkv, int head_dim, int splits, float scale, hipStream_t st) {
-    if (head_dim != AT_D || Hkv < 1 || Hq % Hkv != 0 || splits < 1) return SKV_ERR_UNSUPPORTED;
+                                int Hkv, int head_dim, int splits, float scale, const int32_t* slots, int n_slots,
+                                int sparse_start, int resident_rows, hipStream_t st) {
+    if (head_dim != AT_D || Hkv < 1 || Hq % Hkv != 0 || splits < 1 || splits > 62) return SKV_ERR_UNSUPPORTED;   // (combine: 16 x 128 staging vectors per block)
+    if (slots && (n_slots < 0 || sparse_start < 0 || resident_rows < 8 * n_slots || sparse_start + resident_rows > kv_rows))
+        return SKV_ERR_ARG;
     if (kv_rows < 1 || (long long)kv_rows * AT_D > kv_stride_h || (!kv_len_dev && (kv_len_host < 1 || kv_len_host > kv_rows)))
         return SKV_ERR_ARG;
     const int G = Hq / Hkv;
     dim3 grid(splits, bs * Hkv), block(256);
-    const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float);
+    const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float) + (slots ? (size_t)n_slots * sizeof(int) : 0);
+#define SKV_AT_L(GG, LL)                                                                                        \
+    do {                                                                                                        \
+        static size_t attr_bytes = 0;                                                                           \
+        if (smem > 64 * 1024 && smem > attr_bytes) {                                                            \
+            (void)hipFuncSetAttribute((const void*)skv_attn_partial_kernel<GG, LL>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
+            attr_bytes = smem;                                                                                  \
+        }                                                                                                       \
+        hipLaunchKernelGGL((skv_attn_partial_kernel<GG, LL>), grid, block, smem, st, (const bf16_t*)q,          \
+                           (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows,    \
+                           kv_stride_h, Hkv, splits, scale, slots, n_slots, sparse_start, resident_rows);       \
+    } while (0)
 #define SKV_AT(GG)                                                                                              \
     do {                                                                                                        \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set && smem > 64 * 1024) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)skv_attn_partial_kernel<GG>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        hipLaunchKernelGGL((skv_attn_partial_kernel<GG>), grid, block, smem, st, (const bf16_t*)q,              \
-                           (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows,  \
-                           kv_stride_h, Hkv, splits, scale);                                                                 \
+        if (slots) SKV_AT_L(GG, true);                                                                          \
+        else SKV_AT_L(GG, false);                                                                               \
     } while (0)
     switch (G) {
         case 1: SKV_AT(1); break;
@@ -150,7 +162,7 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         default: return SKV_ERR_UNSUPPORTED;
     }
 #undef SKV_AT
-    if (splits > 62) return SKV_ERR_UNSUPPORTED;   // 16 x 128 staging vectors per block
+#undef SKV_AT_L
     hipLaunchKernelGGL(skv_attn_combine_kernel, dim3(bs * Hq), dim3(128), (size_t)splits * AT_REC * sizeof(float), st,
                        (const float*)ws, (bf16_t*)out, splits);
     return SKV_OK;

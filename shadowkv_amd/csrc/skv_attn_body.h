@@ -1,7 +1,10 @@
 // Body of the split (flash-decoding) attention pass, shared by the standalone kernel (skv_attn.hip) and by the
 // attention role of the fused fetch kernel (skv_rebuild.hip).  See skv_attn.hip for the algorithm.
-//   MASKED: rows of the sparse region whose slot is listed in miss_slots[0 .. n_miss) are skipped (their K / V are
-//   being written by the other roles of the same launch); they are attended by skv_attn_finish_kernel afterwards.
+//   LISTED: of the sparse region [sparse_start, sparse_start + resident_rows) only the chunks in slots[0 .. n_slots) are
+//   attended (8 rows each); the pass runs over a VIRTUAL row range - [0, sparse_start), then the listed chunks, then
+//   the rows behind the region - so every split gets the same share of live rows whatever the list holds.  The fused
+//   fetch launch lists the surviving (hit) chunks: the miss slots are being written by its other roles and are attended
+//   there; a resident set larger than the selection lists the selected slots.
 #pragma once
 #include "skv_common.h"
 
@@ -9,7 +12,7 @@
 #define AT_GROUPS 16  // 16-lane groups per 256-thread workgroup
 #define AT_REC 132     // floats per (head, split) record: acc[128], m, l, 2 pad (16-B aligned rows)
 
-template <int G, bool MASKED, int AT_KB = 4 /* keys per 16-lane group and iteration: 2 * AT_KB row loads in flight */>
+template <int G, bool LISTED, int AT_KB = 4 /* keys per 16-lane group and iteration: 2 * AT_KB row loads in flight */>
 __device__ __forceinline__ void skv_attn_partial_body(
     const bf16_t* __restrict__ q,   // [bs][Hq][128]
     const bf16_t* __restrict__ k,   // [bs][Hkv][rows][128]
@@ -17,22 +20,27 @@ __device__ __forceinline__ void skv_attn_partial_body(
     float* __restrict__ ws,         // [bs*Hkv][G][rec_splits][AT_REC]  (acc[128], m, l)
     int kv_len, long long kv_stride_h /*elements*/, int splits /* ranges the rows are cut into */,
     int rec_splits /* records per head in ws (>= splits) */, int split, int bh, float scale, float* s_dyn,
-    const int32_t* __restrict__ miss_slots, int n_miss, int sparse_start, int sparse_rows) {
+    const int32_t* __restrict__ slots, int n_slots, int sparse_start, int resident_rows) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, grp = wave * 4 + (lane >> 4);
+    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
+    int* s_slots = reinterpret_cast<int*>(s_dyn + AT_GROUPS * G * (AT_D + 2));   // [n_slots] when LISTED
+    const int listed_rows = LISTED ? 8 * n_slots : 0;
+    const int hole = LISTED ? resident_rows - listed_rows : 0;         // rows of the region that are not attended
+    if (LISTED) {
+        for (int i = tid; i < n_slots; i += 256) s_slots[i] = slots[i];
+        __syncthreads();
+        kv_len = kv_len <= sparse_start ? kv_len : sparse_start + listed_rows + max(kv_len - sparse_start - resident_rows, 0);
+    }
     const int per = (kv_len + splits - 1) / splits;
     const int k0 = split * per, k1 = min(k0 + per, kv_len);
-    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
-    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_dyn + AT_GROUPS * G * (AT_D + 2));   // [32] when MASKED
-    if (MASKED) {
-        if (tid < 32) s_mask[tid] = 0u;
-        __syncthreads();
-        for (int i = tid; i < n_miss; i += 256) {
-            const int slot = miss_slots[i];
-            atomicOr(&s_mask[(slot >> 5) & 31], 1u << (slot & 31));
-        }
-        __syncthreads();
-    }
+    auto row_of = [&](int key) __attribute__((always_inline)) -> int {
+        if (!LISTED) return key;
+        const int rel = key - sparse_start;
+        if (rel < 0) return key;
+        if (rel < listed_rows) return sparse_start + 8 * s_slots[rel >> 3] + (rel & 7);
+        return key + hole;
+    };
 
 
     float qf[G][8];
@@ -64,13 +72,8 @@ __device__ __forceinline__ void skv_attn_partial_body(
         for (int i = 0; i < AT_KB; ++i) {
             const int key = key0 + i * AT_GROUPS;
             alive[i] = key < k1;
-            if (MASKED) {
-                const int rel = key - sparse_start;
-                if (rel >= 0 && rel < sparse_rows) alive[i] = alive[i] && !((s_mask[(rel >> 8) & 31] >> ((rel >> 3) & 31)) & 1u);
-            }
-            // dead keys read a row that is certainly valid and finite (their p is 0, but 0 * garbage could be NaN:
-            // a masked slot is being overwritten by the fetch roles of the same launch)
-            const int kc = alive[i] ? key : (MASKED ? 0 : k1 - 1);
+            // keys past the range re-read its last row (their weight is exp(-inf) = 0)
+            const int kc = row_of(alive[i] ? key : k1 - 1);
             kr[i] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc * AT_D);
             vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc * AT_D);
         }
@@ -98,15 +101,14 @@ __device__ __forceinline__ void skv_attn_partial_body(
             float mn = m[g];
 #pragma unroll
             for (int i = 0; i < AT_KB; ++i) mn = fmaxf(mn, sc[i][g]);
-            // m = -inf on the first batch: exp(-inf) = 0.  MASKED: a whole batch can be dead before any live key was
-            // seen (mn = -inf): exp(-inf - -inf) would be NaN
-            const float corr = (MASKED && mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
+            // m = -inf on the first batch: exp(-inf) = 0 (the first key of every batch is alive, so mn is finite)
+            const float corr = __expf(m[g] - mn);
             float lsum = l[g] * corr;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
 #pragma unroll
             for (int i = 0; i < AT_KB; ++i) {
-                const float p = (MASKED && sc[i][g] == -INFINITY) ? 0.f : __expf(sc[i][g] - mn);   // dead keys: 0
+                const float p = __expf(sc[i][g] - mn);   // dead keys: exp(-inf) = 0
                 lsum += p;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

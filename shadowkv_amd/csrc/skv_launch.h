@@ -10,4 +10,5 @@ struct AttnLaunch {
     int kv_rows;             // rows a head owns in the cache buffers: the device-side kv_len is clamped to it
     int G, splits, rec_splits;
     float scale;
+    int resident_sets;       // slots of the sparse region (>= select_sets; the generated rows sit behind resident_sets * 8 rows)
 };

@@ -57,15 +57,16 @@ __device__ __forceinline__ long long chunk_id_at(const void* ids, int ids64, siz
 
 // KS = rank / 32 k-steps (5 for rank 160); every loop below has a compile-time trip count so the
 // compiler batches the global loads of a phase instead of waiting on each one.
-// Optional third role of the launch (in-place layout only): split attention over every row that is NOT a miss slot.
-// Those rows (local, outliers, surviving chunks, generated tokens) are final before this launch starts, so their
-// attention runs on the CUs that the PCIe-bound V fetch leaves idle; the miss rows are attended afterwards by
-// skv_attn_finish_kernel, which also merges the records.
+// Optional third role of the launch (in-place layout only): split attention over the rows that are final before this
+// launch starts (local, outliers, the chunks selected again - dst_slots[0 .. cnt) lists their slots -, generated tokens),
+// on the CUs that the PCIe-bound V fetch leaves idle; the miss rows are attended by the workgroups that build them
+// (TileAttn below), skv_attn_merge_kernel merges the records.
 struct AttnRole {
     const bf16_t* q;          // [bs][Hq][128]
     float* ws;                // [bs*Hq][rec_splits][AT_REC]
     const int* kv_len_dev;    // nullable
     int kv_len_host, kv_rows, splits, rec_splits;
+    int resident_rows;        // rows of the sparse region (resident slots x 8): the generated rows sit behind it
     float scale;
 };
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
         skv_attn_partial_body<AG, true, (AG == 8 ? 1 : 2)>(
             ar.q, out, reinterpret_cast<const bf16_t*>(v_buf), ar.ws, kv_len, out_stride_h, ar.splits, ar.rec_splits,
             bx - rebuild_tiles - land_blocks, bh3, ar.scale, reinterpret_cast<float*>(smem_a),
-            dst_slots + (size_t)bh3 * S + cnt3, S - cnt3, out_row0, S * C);
+            dst_slots + (size_t)bh3 * S, cnt3, out_row0, ar.resident_rows);
         RB_STAMP(7, 0);
         return;
     }
@@ -561,17 +562,18 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
             C != 8 || S % 8 || attn->rec_splits != attn->splits + tiles || v_stride != out_stride_h || out_stride_s != RB_D ||
             out_stride_b != (long long)heads * out_stride_h || v_off != (long long)out_row0 * RB_D)
             return SKV_ERR_UNSUPPORTED;
-        if (attn->kv_rows < out_row0 + S * C || (long long)attn->kv_rows * RB_D > out_stride_h ||
+        if (attn->resident_sets < S || attn->kv_rows < out_row0 + attn->resident_sets * C ||
+            (long long)attn->kv_rows * RB_D > out_stride_h ||
             (!attn->kv_len_dev && (attn->kv_len_host < 1 || attn->kv_len_host > attn->kv_rows)))
             return SKV_ERR_ARG;
         ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->kv_rows,
-                      attn->splits, attn->rec_splits, attn->scale};
+                      attn->splits, attn->rec_splits, attn->resident_sets * C, attn->scale};
         attn_g = attn->G;
         // fused tile: SV staging | K tile (| group partials when they do not fit over the SV staging area)
         const size_t part = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float);
         smem_all = (size_t)RB_D * RB_SV_PITCH + (size_t)RB_ROWS * RB_OUT_PITCH + (size_t)attn_g * 256 /* q */ +
                    (part <= (size_t)RB_D * RB_SV_PITCH ? 0 : part);
-        const size_t need = part + 32 * sizeof(uint32_t);     // resident-rows role
+        const size_t need = part + (size_t)S * sizeof(int);    // resident-rows role: partials + the slot list
         if (need > smem_all) smem_all = need;
         // ONE workgroup per CU (LDS request above half of the 160 KB): measured with in-kernel stamps and A/B runs, a CU
         // with host-memory loads outstanding serves its other memory traffic only when they return, so a second workgroup

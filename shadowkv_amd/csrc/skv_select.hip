@@ -605,15 +605,21 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int64_t* __restrict__ cached,          // [B][S] in: resident ids per slot; out: reordered ids
     int32_t* __restrict__ offsets, int32_t* __restrict__ cnts, int64_t* __restrict__ sel_out,
     int32_t* __restrict__ dst_slots,       // nullable; non-null = in-place layout (see skv_topk_reorder_kernel)
-    int N, int score_stride, int S, int H /* hash size, pow2 >= 2S */, int SP /* pow2 >= S */) {
+    int N, int score_stride, int S, int H /* hash size, pow2 >= 4R */, int SP /* pow2 >= S */,
+    // resident set larger than the selection (in-place layout only): R slots per head (S <= R <= 1024), `cached` is
+    // [B][R], the S - cnt misses replace the least recently selected of the R - cnt slots that were not selected now
+    // (age = steps since the slot's chunk was last selected, saturating at 62; 63 = empty slot; ties -> lowest slot).
+    // R == S: every slot that was not selected is replaced, slot_age is not touched (may be null).
+    int R, int RP /* pow2 >= R */, int32_t* __restrict__ slot_age /* [B][R] */) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_cur = s_hist + T2_BINS * T2_COPIES;        // [SP]   selected landmark slot per output position
     long long* s_id = reinterpret_cast<long long*>(s_cur + SP);   // [SP] its chunk id (-1: not gathered yet)
     int* s_hkeys = reinterpret_cast<int*>(s_id + SP);  // [H]
     int* s_hvals = s_hkeys + H;                       // [H]
-    int* s_byslot = s_hvals + H;                      // [SP]
-    int* s_miss = s_byslot + SP;                      // [SP]
+    int* s_byslot = s_hvals + H;                      // [RP]
+    int* s_age = s_hist;                              // [64] age histogram (the score histogram is dead by then)
+    int* s_miss = s_byslot + RP;                      // [SP]
     int* s_rank = s_miss + SP;                        // [SP]
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
@@ -622,7 +628,8 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     constexpr int NW = 4 * SEGV;                      // 32-bit words (two keys each) per thread
     constexpr int NG = (NW + 15) / 16;                // mask registers: 16 words (32 keys) each
     // everything whose address is known is requested first: the resident id of this thread's slot, the thread's scores
-    const int my_cached = (tid < S) ? (int)cached[(size_t)b * S + tid] : -1;
+    const int my_cached = (tid < R) ? (int)cached[(size_t)b * R + tid] : -1;
+    const int my_age = (R > S && tid < R) ? slot_age[(size_t)b * R + tid] : 0;    // consumed after the classification
     uint32_t w[NW];
     const int j0 = tid * SEGV * 8;                    // first score index of this thread
     if (score != nullptr) {
@@ -644,13 +651,12 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
             s_hkeys[i] = -1;
             s_hvals[i] = 0x7fffffff;
         }
-        for (int i = tid; i < SP; i += T2_THREADS) {
-            s_byslot[i] = -1;
-            s_rank[i] = 0;
-        }
+        for (int i = tid; i < RP; i += T2_THREADS) s_byslot[i] = -1;
+        for (int i = tid; i < SP; i += T2_THREADS) s_rank[i] = 0;
+        if (tid == 0) s_out[6] = 0;
     }
     auto insert_resident = [&]() __attribute__((always_inline)) {
-        if (tid < S && my_cached >= 0) {
+        if (tid < R && my_cached >= 0) {
             unsigned pos = hash_slot(my_cached, H);
             for (int probe = 0; probe < H; ++probe) {
                 int prev = atomicCAS(&s_hkeys[pos], -1, my_cached);
@@ -786,20 +792,48 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         }
         if (my_slot >= 0) s_byslot[my_slot] = my_key;
     }
+    const bool lru = R > S;                               // (uniform)
+    if (lru) {
+        if (tid < 64) s_age[tid] = 0;                     // all reads of the score histogram ended before barrier (D)
+        const unsigned long long hb = __ballot(tid < S && my_slot >= 0);
+        if ((tid & 63) == 0 && hb) atomicAdd(&s_out[6], __builtin_popcountll(hb));
+    }
     __syncthreads();
     TOPK_STAMP(7);
-    // hits ordered by old slot (compaction of s_byslot), misses in selection order
-    const int is_hit_slot = (tid < S && s_byslot[tid] >= 0) ? 1 : 0;
+    // hits ordered by old slot (compaction of s_byslot), misses in selection order; thread tid owns slot tid
+    const int is_hit_slot = (tid < R && s_byslot[tid] >= 0) ? 1 : 0;
     const int is_miss = (tid < S && my_slot < 0) ? 1 : 0;
-    const int hm = block_scan_incl1(is_hit_slot | (is_miss << 16), s_w + 48, tid);
+    // which slots the misses take: R == S every slot that is not a hit; else the S - cnt oldest of them
+    int age = -1, is_gt = (tid < R && !is_hit_slot) ? 1 : 0, is_eq = 0, quota = 0;
+    if (lru) {
+        if (tid < R && !is_hit_slot) {
+            age = my_cached < 0 ? 63 : min(max(my_age, 0), 62);
+            atomicAdd(&s_age[age], 1);
+        }
+        __syncthreads();
+        // every wave finds the age threshold itself: lane l holds the count of age 63 - l (oldest first)
+        const int need = S - s_out[6], lane = tid & 63;
+        const int c = s_age[63 - lane], incl = wave_scan_incl(c);
+        const int first = __builtin_ctzll(__ballot(incl >= need));        // sum of all bins = R - cnt >= need
+        const int thr_age = 63 - first;
+        quota = need - (__builtin_amdgcn_readlane(incl, first) - __builtin_amdgcn_readlane(c, first));
+        is_gt = age > thr_age ? 1 : 0;
+        is_eq = age == thr_age ? 1 : 0;
+    }
+    int ev_pk;   // (rows 48..79 of s_w: the wave maxima of the threshold search are dead)
+    const int hm = block_scan_incl2(is_hit_slot | (is_miss << 16), is_gt | (is_eq << 16), s_w + 48, tid, ev_pk);
     const int hit_incl = hm & 0xffff, miss_incl = hm >> 16;
     if (tid == T2_THREADS - 1) {
         s_out[4] = hit_incl;
         s_out[5] = miss_incl;
     }
     if (is_miss) s_miss[miss_incl - 1] = my_key;
-    int* s_free = s_hvals;  // the hash values are dead after the classification: r-th free slot (ascending)
-    if (dst_slots && tid < S && !is_hit_slot) s_free[tid - hit_incl] = tid;
+    int* s_free = s_hvals;  // the hash values are dead after the classification: r-th slot to refill (ascending)
+    const int gt_excl = (ev_pk & 0xffff) - is_gt, eq_excl = (ev_pk >> 16) - is_eq;
+    const bool evict = is_gt || (is_eq && eq_excl < quota);
+    if (dst_slots && evict) s_free[gt_excl + min(eq_excl, quota)] = tid;
+    if (lru && tid < R)
+        slot_age[(size_t)b * R + tid] = (is_hit_slot || evict) ? 0 : my_cached < 0 ? 63 : min(age + 1, 62);
     __syncthreads();
     TOPK_STAMP(8);
     const int cnt = s_out[4], nm = s_out[5];
@@ -826,10 +860,11 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     if (dst_slots) {
         if (tid < nm) {
             const int key = s_miss[tid], r = s_rank[tid], slot = s_free[r];
-            cached[(size_t)b * S + slot] = (long long)key;
+            cached[(size_t)b * R + slot] = (long long)key;
             offsets[(size_t)b * S + cnt + r] = key;
             dst_slots[(size_t)b * S + cnt + r] = slot;
         }
+        if (is_hit_slot) dst_slots[(size_t)b * S + hit_incl - 1] = tid;   // [0, cnt): the slots of the hits, ascending
         if (tid == 0) cnts[b] = cnt;
         TOPK_STAMP(10);
         return;
@@ -909,8 +944,8 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
 template <int SEGV>
 static int launch_topk2(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
                         int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
-                        int SP, hipStream_t st) {
-    const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 6 + H * 2 + 80 + 16) * sizeof(int);
+                        int SP, int R, int RP, int32_t* slot_age, hipStream_t st) {
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 5 + RP + H * 2 + 80 + 16) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)skv_topk2_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -919,27 +954,29 @@ static int launch_topk2(const void* score, int score_stride, const int64_t* lm_i
         attr_set = true;
     }
     hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
-                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP);
+                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age);
     return SKV_OK;
 }
 
-int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
+int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
-                            int B, int N, int S, hipStream_t st) {
-    if (S < 1 || S > SKV_SEL_THREADS) return SKV_ERR_UNSUPPORTED;
+                            int B, int N, int S, int R, int32_t* slot_age, hipStream_t st) {
+    if (S < 1 || S > SKV_SEL_THREADS || R < S || R > T2_THREADS) return SKV_ERR_UNSUPPORTED;
     if (score != nullptr && (N < S || score_stride < N || (score_stride % 8))) return SKV_ERR_ARG;
-    const int SP = next_pow2(S);
-    const int H = 4 * SP;
+    if (R > S && (!dst_slots || !slot_age)) return SKV_ERR_ARG;      // a larger resident set exists in the in-place layout only
+    const int SP = next_pow2(S), RP = next_pow2(R);
+    const int H = 4 * RP;
 #ifndef SKV_TOPK_V1
     {   // second-generation kernel: scores in registers, <= 16 vectors (128 scores) per thread
         const int per_thread = score ? (score_stride / 8 + T2_THREADS - 1) / T2_THREADS : 1;
-        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
-        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
-        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
-        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
-        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, st);
+        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
+        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
+        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
+        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
+        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
     }
 #endif
+    if (R != S) return SKV_ERR_UNSUPPORTED;   // rows longer than 131,072 scores: first-generation kernel, R == S only
     const size_t base = (size_t)(SP * 4 + H * 2 + 256 + 32 + 8 + 256 * 32) * sizeof(int);
     const size_t with_score = base + (size_t)score_stride * sizeof(bf16_t);
     const bool stage = score != nullptr && with_score <= 150 * 1024;
@@ -961,4 +998,11 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
                            score_stride, S, H, SP);
     }
     return SKV_OK;
+}
+
+int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
+                            int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
+                            int B, int N, int S, hipStream_t st) {
+    return skv_launch_topk_resident(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, S,
+                                    nullptr, st);
 }

@@ -71,6 +71,25 @@ __device__ __forceinline__ int block_scan_incl1(int v, int* s_w, int tid) {
     return v + pre;
 }
 
+// two inclusive scans behind ONE barrier (s_w: two rows of 16); returns the first, the second through v2_incl
+__device__ __forceinline__ int block_scan_incl2(int v1, int v2, int* s_w, int tid, int& v2_incl) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    v1 = wave_scan_incl(v1);
+    v2 = wave_scan_incl(v2);
+    if (lane == 63) {
+        s_w[wave] = v1;
+        s_w[16 + wave] = v2;
+    }
+    __syncthreads();
+    int w1 = lane < 16 ? s_w[lane] : 0, w2 = lane < 16 ? s_w[16 + lane] : 0;
+    w1 = row16_scan_incl(w1);
+    w2 = row16_scan_incl(w2);
+    const int p1 = wave > 0 ? __builtin_amdgcn_readlane(w1, wave - 1) : 0;
+    const int p2 = wave > 0 ? __builtin_amdgcn_readlane(w2, wave - 1) : 0;
+    v2_incl = v2 + p2;
+    return v1 + p1;
+}
+
 // Home slot of a chunk id in the resident-set hash (open addressing, linear probing, H a power of two).  Multiplicative
 // (Fibonacci) hashing: selected chunks come in runs of consecutive ids (neighbouring chunks are attended together), and with
 // id & (H - 1) a run of 100 ids is one 100-slot cluster that every colliding insert / lookup walks with an LDS atomic per

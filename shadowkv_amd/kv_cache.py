@@ -146,7 +146,7 @@ def gram_factorize(k, rank):
 
 class ShadowKVCache_CPU:
     def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
-                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd", v_offload=True):
+                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd", v_offload=True, resident_sets=None):
         if dtype != torch.bfloat16:
             raise ValueError("ShadowKVCache_CPU supports bfloat16 only (as the reference's kernels do)")
         self.config = config
@@ -171,6 +171,14 @@ class ShadowKVCache_CPU:
         self.select_sets = self.sparse_budget // self.chunk_size
         assert self.select_sets * self.chunk_size == self.sparse_budget, \
             f"({self.select_sets}) * {self.chunk_size} != {self.sparse_budget}"
+        # Resident set larger than the selection (in-place layout only; not in the reference, whose resident set IS the
+        # last selection): `resident_sets` slots per head stay in HBM, a selected chunk found in any of them is a hit,
+        # the misses replace the least recently selected slots.  Attention still covers exactly the `select_sets`
+        # selected chunks - same outputs, fewer chunks over PCIe (HBM is plentiful on MI355X, the link is the roof).
+        self.resident_sets = self.select_sets if resident_sets is None else int(resident_sets)
+        if not self.select_sets <= self.resident_sets <= 1024:
+            raise ValueError(f"resident_sets must be in [select_sets = {self.select_sets}, 1024]")
+        self.resident_budget = self.resident_sets * self.chunk_size
 
         L, bs, kv, D, C = self.num_layers, batch_size, self.num_key_value_heads, self.head_dim, chunk_size
         on_gpu = self.device.type == "cuda"
@@ -186,7 +194,7 @@ class ShadowKVCache_CPU:
             self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype)
         else:
             self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device=self.device, dtype=dtype)
-        buf_len = self.sparse_budget + 128 + (self.outlier_chunk + self.local_chunk) * C
+        buf_len = self.resident_budget + 128 + (self.outlier_chunk + self.local_chunk) * C
         self.k_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)
         self.v_cache_buffer = torch.zeros(L, bs, kv, buf_len, D, device=self.device, dtype=dtype)
 
@@ -206,7 +214,10 @@ class ShadowKVCache_CPU:
         self._cnts_layers = torch.zeros(L, self.block_num, device=self.device, dtype=torch.int32)
         self.cnts = self._cnts_layers[0]
         self.signals = torch.zeros(self.block_num, device=self.device, dtype=torch.int32)   # reference attribute; unused
-        self.position_ids = torch.full((L, bs, kv, self.select_sets), -1, device=self.device, dtype=torch.int64)
+        self.position_ids = torch.full((L, bs, kv, self.resident_sets), -1, device=self.device, dtype=torch.int64)
+        # steps since the chunk in a slot was last selected (maintained by the selection kernel when resident_sets >
+        # select_sets; empty slots - position id -1 - count as oldest whatever is stored here)
+        self._slot_age = torch.zeros(L, self.block_num, self.resident_sets, device=self.device, dtype=torch.int32)
         self._select_ws = None
         # staging buffers of the two-phase (spin-free) chunk movement: moved hit chunks of one layer.  `temp` is the
         # reference's attribute of the same shape (kv_cache.py:612-620) and IS the V staging buffer; `output` is the
@@ -239,6 +250,8 @@ class ShadowKVCache_CPU:
         self.gen_offset = 0
         self.prefill_local = 0
         self.prefilled_batch = 0
+        self.position_ids.fill_(-1)
+        self._slot_age.zero_()
         self._select_ws = None          # sized for the previous landmark count
 
     def H2D(self):
@@ -338,7 +351,7 @@ class ShadowKVCache_CPU:
         sel = outlier_idx[..., None, None].expand(-1, -1, -1, C, D)
         n_out = self.outlier_chunk * C
         self.sparse_start = self.prefill_local + n_out
-        self.sparse_end = self.sparse_start + self.sparse_budget
+        self.sparse_end = self.sparse_start + self.resident_budget   # rows of the generated tokens start here
         self.kernel_offset = self.sparse_start * D
         self.kernel_stride = self.v_cache_buffer[layer_idx].shape[-2] * D
         kbuf[:, :, self.prefill_local:self.sparse_start].copy_(k_ctx.gather(2, sel).view(bsz, kv, n_out, D))
@@ -351,21 +364,22 @@ class ShadowKVCache_CPU:
         self.register_k_landmark(means.gather(2, rest_idx.unsqueeze(-1).expand(-1, -1, -1, D)), rest_idx, layer_idx)
 
         chosen = self._score_landmarks_torch(layer_idx, b0, bsz, last_query_states)
-        self.position_ids[layer_idx][b0:b0 + bsz].copy_(chosen)
-        pos = self.position_ids[layer_idx][b0:b0 + bsz]
+        self.position_ids[layer_idx][b0:b0 + bsz, :, :S].copy_(chosen)   # slots [S, resident_sets) start empty (-1)
+        pos = self.position_ids[layer_idx][b0:b0 + bsz, :, :S]
         assert pos.max() < self.chunks, f"position_ids exceed the max_length {pos.max()}"
         assert pos.min() >= 0, f"position_ids exceed the min_length {pos.min()}"
         tok = (chosen.unsqueeze(-1) * C + torch.arange(C, device=chosen.device)).view(bsz, kv, -1)
         tok = tok.unsqueeze(-1).expand(-1, -1, -1, D)
-        vbuf[:, :, self.sparse_start:self.sparse_end].copy_(new_v_cache.gather(-2, tok), non_blocking=True)
-        kbuf[:, :, self.sparse_start:self.sparse_end].copy_(key_states_roped.gather(-2, tok), non_blocking=True)
+        sel_end = self.sparse_start + self.sparse_budget
+        vbuf[:, :, self.sparse_start:sel_end].copy_(new_v_cache.gather(-2, tok), non_blocking=True)
+        kbuf[:, :, self.sparse_start:sel_end].copy_(key_states_roped.gather(-2, tok), non_blocking=True)
 
         if layer_idx == self.num_layers - 1:
             assert self.sparse_budget < incoming
             self.prefilled_batch += bsz
             if self.prefilled_batch == self.batch_size:
                 self.kv_offset += incoming
-                assert not torch.any(self.position_ids == -1), \
+                assert not torch.any(self.position_ids[..., :S] == -1), \
                     f"The cache for offloading is not built correctly, {self.position_ids}"
 
     # ------------------------------------------------------------------ decode (native)
@@ -377,6 +391,7 @@ class ShadowKVCache_CPU:
         Returns position_ids[layer_idx] (reordered in place: hits by old slot, then misses by id);
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
+        self._reference_layout_only("get_retrieval_position_ids")
         self.cnts = self._cnts_layers[layer_idx]
         if self.incoming_q_len != 1:
             raise ValueError("decode-time selection expects q_len == 1 (the reference's top-k over "
@@ -394,6 +409,11 @@ class ShadowKVCache_CPU:
         self._stage_hits(layer_idx)
         return self.position_ids[layer_idx]
 
+    def _reference_layout_only(self, what):
+        if self.resident_sets != self.select_sets:
+            raise RuntimeError(f"{what}: the reference's slot order needs resident_sets == select_sets; a larger "
+                               "resident set exists in the in-place layout only (select_fetch[_attend]_inplace)")
+
     def _stage_hits(self, layer_idx):
         """Phase 1 of the chunk movement for BOTH buffers of a layer, once per (layer, selection): every hit
         chunk whose slot changes is copied to the staging buffers.  Must run on the stream that produced
@@ -409,6 +429,7 @@ class ShadowKVCache_CPU:
         region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream): lands the
         hit chunks staged by get_retrieval_position_ids and pulls the misses over PCIe with plain 16-B loads
         (49-56 GB/s measured, the DMA ceiling; tools/pcie_probe.hip)."""
+        self._reference_layout_only("get_value_cache")
         vhost = self.v_cache_cpu[layer_idx]
         vbuf = self.v_cache_buffer[layer_idx]
         check(lib().skv_land_chunks(ptr(vhost), ptr(vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
@@ -419,6 +440,7 @@ class ShadowKVCache_CPU:
     def get_key_cache(self, layer_idx, position_ids, rope_func, cos_sin_cache):
         """Hit chunks moved to their new slots, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
         region (kv_cache.py:1108-1176), one launch.  `rope_func` is unused, as in the reference."""
+        self._reference_layout_only("get_key_cache")
         kbuf = self.k_cache_buffer[layer_idx]
         tensor_op.rebuild_keys(self.U[layer_idx], self.SV[layer_idx], cos_sin_cache, position_ids, self.cnts, kbuf,
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
@@ -428,6 +450,7 @@ class ShadowKVCache_CPU:
         """get_value_cache + get_key_cache of one layer as a single launch on the current stream (K rebuild
         tiles and V landing blocks run side by side inside one grid; no copy_stream fork/join).  Same bytes in
         both caches as the two separate calls."""
+        self._reference_layout_only("fetch_kv")
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
@@ -462,7 +485,8 @@ class ShadowKVCache_CPU:
                                           ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
                                           ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
                                           self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                                          1.0 / math.sqrt(128), st), "select_chunks_inplace")
+                                          self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128), st),
+              "select_chunks_inplace")
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
@@ -473,6 +497,14 @@ class ShadowKVCache_CPU:
                                      self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
                                      kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
               "fetch_kv_inplace")
+
+    def attend_slot_args(self):
+        """Keyword arguments for tensor_op.sparse_attention_decode after select_fetch_inplace: with a resident set larger
+        than the selection only the selected slots of the sparse region are attended."""
+        if self.resident_sets == self.select_sets:
+            return {}
+        return dict(slots=self._dst_slots, select_sets=self.select_sets, sparse_start=self.sparse_start,
+                    resident_sets=self.resident_sets)
 
     OVERLAP_SPLITS = 24   # split pass over the resident rows inside the fetch launch (+ one record per miss tile)
 
@@ -518,7 +550,8 @@ class ShadowKVCache_CPU:
                                           ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
                                           ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
                                           self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                                          1.0 / math.sqrt(128), st), "select_chunks_inplace")
+                                          self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128), st),
+              "select_chunks_inplace")
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
@@ -529,7 +562,8 @@ class ShadowKVCache_CPU:
                                           ptr(kv_len_dev), int(kv_len), buf_rows, U.shape[0], self.num_key_value_heads, Hq,
                                           U.shape[1], D, self.rank, self.select_sets, self.chunk_size,
                                           cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
-                                          self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA, scale, st),
+                                          self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA,
+                                          self.resident_sets, scale, st),
               "fetch_kv_attn_inplace")
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
         check(L.skv_attn_finish_inplace(ptr(ws), ptr(self.cnts), ptr(out), bs, Hq, self.num_key_value_heads,

@@ -79,7 +79,8 @@ def build_cos_sin_cache(cfg, max_pos, device, dtype):
 class DecoderLM:
     def __init__(self, cfg=LLAMA_3_1_8B, batch_size=1, max_length=64 * 1024, device="cuda:0", dtype=torch.bfloat16,
                  attn_mode="shadowkv_cpu", sparse_budget=2048, rank=160, chunk_size=8, random_init=True, seed=1234,
-                 num_layers=None, chunk_layout="reference", v_offload=True, overlap_attention=False, max_new_tokens=1024):
+                 num_layers=None, chunk_layout="reference", v_offload=True, overlap_attention=False, max_new_tokens=1024,
+                 resident_sets=None):
         if chunk_layout not in ("reference", "inplace"):
             raise ValueError("chunk_layout must be 'reference' (hits compacted to the front, the reference's slot order) "
                              "or 'inplace' (hits keep their slots, misses take the freed slots)")
@@ -125,7 +126,7 @@ class DecoderLM:
         else:
             self.kv_cache = ShadowKVCache_CPU(_CacheCfg, batch_size=batch_size, max_length=max_length, device=device,
                                               dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size,
-                                              rank=rank, v_offload=v_offload)
+                                              rank=rank, v_offload=v_offload, resident_sets=resident_sets)
         self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
 
     def weight_bytes(self):
@@ -220,12 +221,14 @@ class DecoderLM:
             if not full and self.chunk_layout == "inplace" and self.overlap_attention and c.can_overlap_attention():
                 attn = c.select_fetch_attend_inplace(l, q, self.cos_sin_cache, kv_len=kv_len, kv_len_dev=kv_len_dev)
             else:
+                slot_args = {}
                 if not full and self.chunk_layout == "inplace":
                     c.select_fetch_inplace(l, q, self.cos_sin_cache)
+                    slot_args = c.attend_slot_args()
                 elif not full:
                     ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
                     c.fetch_kv(l, ids, self.cos_sin_cache)
-                attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev)
+                attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev, **slot_args)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)
             # residual add + RMSNorm ride in the gate/up GEMV's block-cooperative prologue (one launch when bs == 1
             # and hidden == 4096, bit-identical to add_rmsnorm + GEMV; otherwise norm_linear_decode splits it)

@@ -228,11 +228,14 @@ def attention_workspace(device, bs, Hq, splits):
     return ws
 
 
-def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, splits=None, out=None):
+def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, splits=None, out=None, slots=None,
+                            select_sets=0, sparse_start=0, resident_sets=0):
     """softmax(q K^T / sqrt(D)) V for q_len == 1 over the first kv_len rows of the cache views.
     q [bs, Hq, 1, D] or [bs, Hq, D]; k_cache / v_cache [bs, Hkv, rows, D] views of contiguous
     [bs, Hkv, buf_rows, D] buffers (what get_key_cache / get_value_cache return).  Returns
-    [bs, 1, Hq, D] like flash_attn_with_kvcache's output for q [bs, 1, Hq, D]."""
+    [bs, 1, Hq, D] like flash_attn_with_kvcache's output for q [bs, 1, Hq, D].
+    slots (int32 [bs * Hkv, select_sets], with sparse_start / resident_sets): a resident set larger than the selection -
+    of the rows [sparse_start, sparse_start + 8 * resident_sets) only the listed chunks are attended."""
     bs, Hq = q.shape[0], q.shape[1]
     D = q.shape[-1]
     Hkv = k_cache.shape[1]
@@ -253,6 +256,12 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     ws = attention_workspace(q.device, bs, Hq, splits)
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
+    if slots is not None:
+        check(lib().skv_sparse_attention_slots(ptr(q), ptr(k_cache), ptr(v_cache), ptr(out), ptr(ws), ptr(kv_len_dev),
+                                               int(kv_len), rows, k_cache.stride(1), bs, Hq, Hkv, D, splits,
+                                               1.0 / math.sqrt(D), ptr(slots), int(select_sets), int(sparse_start),
+                                               int(resident_sets), current_stream_handle()), "sparse_attention_slots")
+        return out
     check(lib().skv_sparse_attention(ptr(q), ptr(k_cache), ptr(v_cache), ptr(out), ptr(ws), ptr(kv_len_dev),
                                      int(kv_len), rows, k_cache.stride(1), bs, Hq, Hkv, D, splits, 1.0 / math.sqrt(D),
                                      current_stream_handle()), "sparse_attention")

@@ -118,7 +118,7 @@ def test_select_chunks_inplace(blocks, G, N, S, overlap):
     qd, lmd, lid = q.to(DEV), lm.to(DEV), lm_idx.to(DEV)
     L.check(L.lib().skv_select_chunks_inplace(qd.data_ptr(), lmd.data_ptr(), lid.data_ptr(), c.data_ptr(), mids.data_ptr(),
                                               slots.data_ptr(), cnt.data_ptr(), ws.data_ptr(), 0, sel_out.data_ptr(),
-                                              blocks, G, N, S, ALPHA, _stream()), "select_chunks_inplace")
+                                              blocks, G, N, S, S, 0, ALPHA, _stream()), "select_chunks_inplace")
     torch.cuda.synchronize()
     assert torch.equal(sel_out.cpu(), sel)
     assert cnt.cpu().tolist() == cnts
@@ -127,11 +127,13 @@ def test_select_chunks_inplace(blocks, G, N, S, overlap):
         k = cnts[b]
         assert mids[b, k:].cpu().tolist() == miss_ids[b]
         assert slots[b, k:].cpu().tolist() == dst[b]
-        assert torch.all(mids[b, :k] == -7) and torch.all(slots[b, :k] == -7)     # nothing written for hits
+        assert torch.all(mids[b, :k] == -7)                                       # no miss id written for hits
+        assert slots[b, :k].cpu().tolist() == sorted(set(range(S)) - set(dst[b]))  # [0, cnt): the hits' slots, ascending
 
 
-def _select_from_scores(score, lm_idx, cached, S, inplace=False):
-    """skv_select_from_scores on the device: (selected ids, cached after, offsets, cnts, dst_slots)."""
+def _select_from_scores(score, lm_idx, cached, S, inplace=False, age=None):
+    """skv_select_from_scores on the device: (selected ids, cached after, offsets, cnts, dst_slots[, slot ages]).
+    cached [blocks, R]; R > S (a resident set larger than the selection) needs inplace and the slot ages."""
     L = _lib()
     blocks, N = score.shape
     stride = (N + 7) // 8 * 8
@@ -142,9 +144,13 @@ def _select_from_scores(score, lm_idx, cached, S, inplace=False):
     cnt = torch.zeros(blocks, dtype=torch.int32, device=DEV); sel = torch.zeros(blocks, S, dtype=torch.int64, device=DEV)
     dst = torch.full((blocks, S), -7, dtype=torch.int32, device=DEV) if inplace else None
     lid = lm_idx.to(DEV) if lm_idx is not None else None
+    aged = age.to(DEV) if age is not None else None
     L.check(L.lib().skv_select_from_scores(scd.data_ptr(), stride, L.ptr(lid), c.data_ptr(), off.data_ptr(), L.ptr(dst),
-                                           cnt.data_ptr(), sel.data_ptr(), blocks, N, S, _stream()), "select_from_scores")
+                                           cnt.data_ptr(), sel.data_ptr(), blocks, N, S, cached.shape[1], L.ptr(aged),
+                                           _stream()), "select_from_scores")
     torch.cuda.synchronize()
+    if age is not None:
+        return sel.cpu(), c.cpu(), off.cpu(), cnt.cpu(), dst.cpu(), aged.cpu()
     return sel.cpu(), c.cpu(), off.cpu(), cnt.cpu(), (dst.cpu() if inplace else None)
 
 
@@ -221,6 +227,64 @@ def test_select_from_scores_edge_cases(blocks, N, S, kind):
     r = _select_from_scores(score, lm_idx, cached, S)
     assert torch.equal(r[0], o[0]), "selected ids"
     assert torch.equal(r[1], o[1]) and torch.equal(r[2], o[2]) and torch.equal(r[3], o[3])
+
+
+def _resident_expected(cached, age, sel, S):
+    """Model of the resident-set policy (include/shadowkv_hip.h, skv_select_chunks_inplace): one head, one step.
+    cached [R] ids per slot (-1 empty), age [R], sel = the S selected ids.  Returns (cached', age', cnt, miss ids,
+    slots of the misses, slots of the hits)."""
+    R = len(cached)
+    pos = {}
+    for slot, cid in enumerate(cached):
+        if cid >= 0 and cid not in pos:
+            pos[cid] = slot                                              # duplicates: the lowest slot answers
+    hit_slots = sorted(pos[c] for c in sel if c in pos)
+    misses = sorted(c for c in sel if c not in pos)
+    eff = [63 if cached[s] < 0 else min(max(age[s], 0), 62) for s in range(R)]
+    cand = [s for s in range(R) if s not in set(hit_slots)]
+    evicted = sorted(sorted(cand, key=lambda s: (-eff[s], s))[:len(misses)])
+    new_c, new_a = list(cached), [0] * R
+    for s in range(R):
+        if s in set(hit_slots) or s in set(evicted):
+            new_a[s] = 0
+        else:
+            new_a[s] = 63 if cached[s] < 0 else min(eff[s] + 1, 62)
+    for slot, cid in zip(evicted, misses):
+        new_c[slot] = cid
+    return new_c, new_a, len(hit_slots), misses, evicted, hit_slots
+
+
+@pytest.mark.parametrize("blocks,N,S,R", [(4, 6000, 256, 512), (2, 3000, 64, 200), (2, 9000, 256, 1024), (2, 2000, 128, 129)])
+def test_select_resident_set_larger_than_the_selection(blocks, N, S, R):
+    """R resident slots per head, S selected per step (in-place layout): over a run of steps whose selections overlap,
+    the slot -> id map, the slot ages, the hit counts, the miss ids, the slots the misses take (least recently selected
+    first, ties and empty slots -> lowest slot) and the slots of the hits equal the policy model exactly; the selected
+    SET is what the R == S kernel selects."""
+    g = torch.Generator().manual_seed(N + R)
+    lm_idx = torch.stack([torch.sort(torch.randperm(N + 48, generator=g)[:N]).values for _ in range(blocks)]).to(torch.int64)
+    cached = torch.full((blocks, R), -1, dtype=torch.int64)
+    age = torch.zeros(blocks, R, dtype=torch.int32)
+    # start like a prefill: S slots filled, the rest empty; block 1 starts with old, saturated and tied ages
+    for b in range(blocks):
+        cached[b, :S] = lm_idx[b][torch.randperm(N, generator=g)[:S]]
+    if blocks > 1:
+        cached[1] = lm_idx[1][torch.randperm(N, generator=g)[:R]]
+        age[1] = torch.randint(55, 70, (R,), generator=g, dtype=torch.int32)     # beyond 62: clamped
+    logit = torch.randn(blocks, N, generator=g) * 2
+    for step in range(10):
+        logit = logit + torch.randn(blocks, N, generator=g) * (0.6 if step % 4 else 2.5)     # every 4th step: a jump
+        score = torch.softmax(logit, dim=-1).bfloat16()
+        sel_ref = _select_from_scores(score, lm_idx, cached[:, :S].contiguous(), S, inplace=True)[0]
+        sel, c_new, off, cnt, dst, age_new = _select_from_scores(score, lm_idx, cached, S, inplace=True, age=age)
+        assert torch.equal(sel, sel_ref), "a larger resident set must not change what is selected"
+        for b in range(blocks):
+            ec, ea, ecnt, emiss, eslots, ehit = _resident_expected(cached[b].tolist(), age[b].tolist(), sel[b].tolist(), S)
+            assert int(cnt[b]) == ecnt, (step, b)
+            assert c_new[b].tolist() == ec, (step, b)
+            assert age_new[b].tolist() == ea, (step, b)
+            assert off[b, ecnt:].tolist() == emiss and dst[b, ecnt:].tolist() == eslots and dst[b, :ecnt].tolist() == ehit
+        cached, age = c_new, age_new
+    assert int((cached >= 0).sum()) > blocks * S          # the set grew past the selection
 
 
 def test_select_chunks_ties():

@@ -255,7 +255,7 @@ def test_overlapped_attention_equals_fetch_then_attend(case):
             assert bool((err <= tol).all()), f"step {t} {name}: attention exceeds the bound by {float((err - tol).max())}"
 
 
-def _headline_cache(kv_heads, glm, L=8192, seed=11):
+def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None):
     """ShadowKVCache_CPU with the headline layout (budget 2,048 -> S = 256, 48 outlier chunks, sparse region rows
     [448, 2496), 96 generated rows) over an L-token synthetic context whose keys are exactly rank 160."""
     from shadowkv_amd import llama, tensor_op
@@ -263,7 +263,7 @@ def _headline_cache(kv_heads, glm, L=8192, seed=11):
     mc = llama.ModelConfig(num_hidden_layers=1, num_key_value_heads=kv_heads, rope_style="glm" if glm else "neox",
                            rope_theta=10000.0 if glm else 500000.0)
     cache = ShadowKVCache_CPU(mc, batch_size=1, max_length=L, device=DEV, dtype=torch.bfloat16, sparse_budget=2048,
-                              chunk_size=8, rank=160)
+                              chunk_size=8, rank=160, resident_sets=resident_sets)
     g = torch.Generator(device=DEV).manual_seed(seed)
     D, r = 128, 160
     cs = llama.build_cos_sin_cache(mc, L + 256, torch.device(DEV), torch.bfloat16)
@@ -358,3 +358,72 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     assert bool(((out2.view(1, Hq, D).cpu().float() - a32).abs() <= tol).all()), "kv_len on the device"
     with pytest.raises(ValueError):
         cache.select_fetch_attend_inplace(0, q, cs, kv_len=2593)
+
+
+@pytest.mark.parametrize("kv_heads,glm,overlap", [(8, False, True), (8, False, False), (4, True, True)])
+def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm, overlap):
+    """resident_sets = 512 > select_sets = 256 (in-place layout): over a walk of queries, step by step against a cache
+    with the reference's resident set (256) fed the same queries - the selected sets are identical, the hit counts are
+    never lower, every occupied slot holds its chunk's V rows byte for byte (also the slots that are resident but not
+    selected), and the attention output equals the oracle's F32 attention over [local + outliers | the selected chunks |
+    generated rows] of the device's own K / V bytes at 1e-3 |ref| + half a bf16 ulp - with the attention inside the fetch
+    launch (overlap) and with the standalone pass over the slot list."""
+    from shadowkv_amd import tensor_op
+    R = 512
+    big, cs, g = _headline_cache(kv_heads, glm, resident_sets=R)
+    ref, _, _ = _headline_cache(kv_heads, glm)
+    Hq, D, C, S = 32, 128, 8, big.select_sets
+    assert big.sparse_end == 448 + R * C and big.k_cache_buffer.shape[-2] == 448 + R * C + 96 and ref.sparse_end == 2496
+    gen = 2
+    newk = torch.randn(1, kv_heads, gen, D, device=DEV, generator=g).bfloat16()
+    newv = torch.randn(1, kv_heads, gen, D, device=DEV, generator=g).bfloat16()
+    for c in (big, ref):
+        c.k_cache_buffer[0][:, :, c.sparse_end:c.sparse_end + gen] = newk
+        c.v_cache_buffer[0][:, :, c.sparse_end:c.sparse_end + gen] = newv
+    q32 = torch.randn(1, Hq, 1, D, device=DEV, generator=g) * 1.5
+    vhost = big.v_cache_cpu[0][0]
+    more_hits = 0
+    for step in range(6):
+        q32 = q32 + 0.45 * torch.randn(q32.shape, device=DEV, generator=g)
+        q = q32.bfloat16()
+        outs = []
+        for c in (big, ref):
+            kv_len = c.sparse_end + gen
+            if overlap:
+                outs.append(c.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len))
+            else:
+                c.select_fetch_inplace(0, q, cs)
+                outs.append(tensor_op.sparse_attention_decode(q, c.k_cache_buffer[0], c.v_cache_buffer[0], kv_len=kv_len,
+                                                              **c.attend_slot_args()))
+        torch.cuda.synchronize()
+        slots = big._dst_slots.view(kv_heads, S).cpu().long()                # the S attended slots per head
+        ids_big = big.position_ids[0][0].cpu()
+        sel_big = torch.gather(ids_big, 1, slots).sort(dim=-1).values
+        assert torch.equal(sel_big, ref.position_ids[0][0].cpu().sort(dim=-1).values), f"step {step}: selected sets differ"
+        hb, hr = big._cnts_layers[0].cpu(), ref._cnts_layers[0].cpu()
+        assert bool((hb >= hr).all()), (step, hb.tolist(), hr.tolist())
+        more_hits += int((hb - hr).sum())
+        vbuf = big.v_cache_buffer[0].cpu()
+        for h in range(kv_heads):                                            # every occupied slot: its chunk's V rows
+            occ = (ids_big[h] >= 0).nonzero().flatten()
+            want = vhost[h][ids_big[h][occ]].view(len(occ), C, D)
+            got = vbuf[0, h, big.sparse_start:big.sparse_end].view(R, C, D)[occ]
+            assert_bits_equal(got, want, f"step {step} head {h}: V rows of the resident slots")
+        for name, c, o in (("512 resident", big, outs[0]), ("256 resident", ref, outs[1])):
+            # F32 oracle over this cache's own K / V bytes: [local + outliers | the S attended chunks | generated rows]
+            sl = c._dst_slots.view(kv_heads, S).cpu().long()
+            rows = (c.sparse_start + sl.unsqueeze(-1) * C + torch.arange(C)).view(kv_heads, S * C)
+            kb, vb = c.k_cache_buffer[0].cpu(), c.v_cache_buffer[0].cpu()
+
+            def view_of(buf):
+                sel_rows = torch.gather(buf[0], 1, rows.unsqueeze(-1).expand(-1, -1, D))
+                return torch.cat([buf[0][:, :c.sparse_start], sel_rows, buf[0][:, c.sparse_end:c.sparse_end + gen]],
+                                 dim=1).unsqueeze(0).contiguous()
+            kview, vview = view_of(kb), view_of(vb)
+            _, a32 = oracle.sparse_attention(q.cpu().view(1, Hq, D).contiguous(), kview, vview, kview.shape[2], 1 / math.sqrt(D))
+            tol = 1e-3 * a32.abs() + 2.0 ** -8 * a32.abs() + 1e-5
+            err = (o.view(1, Hq, D).cpu().float() - a32).abs()
+            assert bool((err <= tol).all()), f"step {step}, {name}: attention exceeds the bound by {float((err - tol).max())}"
+    assert more_hits > 0, "the larger resident set never produced an extra hit"
+    with pytest.raises(RuntimeError):
+        big.get_retrieval_position_ids(0, q)
