@@ -10,8 +10,9 @@
 int main(int argc, char** argv) {
     const bool inplace = argc > 1 && !strcmp(argv[1], "inplace");
     const int B = 8, N = 15560, S = 256, stride = (N + 7) & ~7;
+    const int R = argc > 6 ? atoi(argv[6]) : S;     // argv[6]: resident slots per head (> S: least-recently-selected replacement)
     std::vector<uint16_t> sc((size_t)B * stride);
-    std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * S);
+    std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * R);
     srand(3);
     // scores shaped like the decode step's softmax probabilities: log-normal, sigma from argv (0 = flat +-40 %)
     const float sigma = argc > 4 ? atof(argv[4]) : 0.f;
@@ -24,7 +25,7 @@ int main(int argc, char** argv) {
         }
         uint32_t u; memcpy(&u, &p, 4); v = u >> 16;
     }
-    if (argc > 5) {   // argv[5] = run length: the top scores sit in runs of that many consecutive landmark slots (attention locality)
+    if (argc > 5 && atoi(argv[5]) > 0) {   // argv[5] = run length: the top scores sit in runs of that many consecutive landmark slots (attention locality)
         const int runlen = atoi(argv[5]), nruns = (S + runlen - 1) / runlen;
         for (int b = 0; b < B; ++b)
             for (int r = 0; r < nruns; ++r) {
@@ -36,7 +37,10 @@ int main(int argc, char** argv) {
             }
     }
     for (int b = 0; b < B; ++b) for (int j = 0; j < N; ++j) lm[(size_t)b * N + j] = j + j / 300;
-    for (int b = 0; b < B; ++b) for (int j = 0; j < S; ++j) cached[(size_t)b * S + j] = (j * 61) % N;
+    // resident ids: random chunk ids (an arithmetic progression like (61 j) mod N is a worst case of the multiplicative
+    // hash at table sizes 1024 / 2048 - stride 0.70007 of the table - and doubles the hash-build and lookup phases)
+    for (int b = 0; b < B; ++b) for (int j = 0; j < R; ++j) cached[(size_t)b * R + j] = (argc > 7 ? (j * 61) % N : rand() % N);
+    int32_t* dage; hipMalloc(&dage, (size_t)B * R * 4); hipMemset(dage, 0, (size_t)B * R * 4);
     uint16_t* dsc; int64_t *dlm, *dc, *dsel; int32_t *doff, *dcnt, *dslot;
     hipMalloc(&dsc, sc.size() * 2); hipMalloc(&dlm, lm.size() * 8); hipMalloc(&dc, cached.size() * 8); hipMalloc(&dsel, cached.size() * 8);
     hipMalloc(&doff, B * S * 4); hipMalloc(&dcnt, B * 4); hipMalloc(&dslot, B * S * 4);
@@ -58,7 +62,7 @@ int main(int argc, char** argv) {
             skv_launch_topk_reorder(dsc2, stride, dlm2, nullptr, dc2, doff2, dcnt2, nullptr, nullptr, B, N, S, 0);
             hipDeviceSynchronize();
         }
-        int rc = skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
+        int rc = skv_launch_topk_resident(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
         hipDeviceSynchronize();
 #ifdef SKV_TOPK_STAMPS
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
@@ -78,7 +82,7 @@ int main(int argc, char** argv) {
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int it = 0; it < 50; ++it) skv_launch_topk_reorder(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, 0);
+    for (int it = 0; it < 50; ++it) skv_launch_topk_resident(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("back-to-back launches: %.2f us per launch (event time, includes launch boundary)\n", ms * 1e3 / 50);
