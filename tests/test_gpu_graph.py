@@ -7,13 +7,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _make(seed=5, glm=False, layout="reference", overlap=False):
+def _make(seed=5, glm=False, layout="reference", overlap=False, resident_sets=None, batch=1):
     from shadowkv_amd import llama
     cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
                             num_attention_heads=8, num_key_value_heads=2, vocab_size=2000,
                             qkv_bias=glm, rope_style="glm" if glm else "neox")
-    m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
-                        seed=seed, chunk_layout=layout, overlap_attention=overlap)
+    m = llama.DecoderLM(cfg=cfg, batch_size=batch, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
+                        seed=seed, chunk_layout=layout, overlap_attention=overlap, resident_sets=resident_sets)
     llama.build_synthetic_context(m, 4608, seed=77)
     return m, llama
 
@@ -347,6 +347,60 @@ def test_overlapped_attention_graph_equals_eager_and_decodes_like_the_plain_path
     assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
     assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
     assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
+
+
+@pytest.mark.parametrize("overlap,batch", [(True, 1), (False, 1), (False, 2)])
+def test_resident_set_larger_than_the_selection_decodes_like_the_reference_set(overlap, batch):
+    """resident_sets = 80 > select_sets = 32 on the decode step itself: under teacher forcing the model attends the same
+    chunk sets as the model with the reference's resident set (its position_ids, sorted, equal the ids in the attended
+    slots) and its logits agree to the accuracy of the attention's f32 sums; hit counts are never lower and the set does
+    produce extra hits; the captured step replays the eager one bit for bit (tokens, slot map, ages, cache bytes)."""
+    steps, R = 8, 80
+    m0, llama = _make(layout="inplace", overlap=overlap, batch=batch)
+    m1, _ = _make(layout="inplace", overlap=overlap, batch=batch, resident_sets=R)
+    c0, c1 = m0.kv_cache, m1.kv_cache
+    S = c0.select_sets
+    assert c1.resident_sets == R and c1.position_ids.shape[-1] == R and c1.sparse_end == c0.sparse_end + (R - S) * 8
+    assert overlap == (c1.can_overlap_attention() and m1.overlap_attention)
+    table = llama.make_walk_table(m0, steps, seed=3)
+    tok = torch.full((batch, 1), 17, device=DEV)
+    extra = 0
+    for i in range(steps):
+        outs = []
+        for m in (m0, m1):
+            c = m.kv_cache
+            row = c.sparse_end + c.gen_offset
+            lg = m.forward_fused(tok, m.get_ctx(tok), torch.tensor([row], device=DEV), kv_len=row + 1, q_table=table[i])
+            c.note_kv_appended(1)
+            outs.append(lg[:, -1])
+        # the last layer's attended slots hold the reference set's ids
+        slots = c1._dst_slots.view(batch, c1.num_key_value_heads, S).long()
+        attended = torch.gather(c1.position_ids[-1], -1, slots).sort(dim=-1).values
+        assert torch.equal(attended, c0.position_ids[-1].sort(dim=-1).values), i
+        assert bool((c1._cnts_layers >= c0._cnts_layers).all()), i
+        extra += int((c1._cnts_layers - c0._cnts_layers).sum())
+        rel = float((outs[0] - outs[1]).norm() / outs[0].norm())
+        assert rel < 2e-2, (i, rel)
+        tok = outs[0].argmax(dim=-1, keepdim=True)
+    assert extra > 0
+    # eager vs captured with the larger set
+    m2, _ = _make(layout="inplace", overlap=overlap, batch=batch, resident_sets=R)
+    m3, _ = _make(layout="inplace", overlap=overlap, batch=batch, resident_sets=R)
+    t = torch.full((batch, 1), 17, device=DEV)
+    toks2 = []
+    for i in range(steps):
+        t = m2.decode_step(t, temperature=0.0, q_table=table[i])
+        toks2.append(t.flatten().tolist())
+    dec = llama.GraphDecoder(m3, temperature=0.0, walk_table=table)
+    dec.token.copy_(torch.full((batch, 1), 17, device=DEV))
+    warm = dec.capture(warmup=2)
+    toks3 = [dec.step().flatten().tolist() for _ in range(steps - warm)]
+    torch.cuda.synchronize()
+    assert toks3 == toks2[warm:]
+    c2, c3 = m2.kv_cache, m3.kv_cache
+    assert torch.equal(c2.position_ids, c3.position_ids) and torch.equal(c2._slot_age, c3._slot_age)
+    assert torch.equal(c2.k_cache_buffer.view(torch.int16), c3.k_cache_buffer.view(torch.int16))
+    assert torch.equal(c2.v_cache_buffer.view(torch.int16), c3.v_cache_buffer.view(torch.int16))
 
 
 def test_sample_advance_kernel_distribution_and_counters():
