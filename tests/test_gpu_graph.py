@@ -119,7 +119,8 @@ def test_gemv_against_f32_reference(N, K, silu):
                                         (16, 4096, 4096, False), (5, 1000, 13696, False), (7, 2 * 1003, 1024, True),
                                         (4, 128256, 4096, False), (17, 4096, 4096, False), (24, 6144, 4096, False),
                                         (24, 28672, 4096, True), (32, 4096, 14336, False), (31, 2 * 1003, 1024, True),
-                                        (24, 1000, 13696, False)])
+                                        (24, 1000, 13696, False), (12, 6144, 4096, False), (12, 6150, 1024, False),
+                                        (20, 2 * 9001, 1024, True), (16, 28672, 4096, True)])
 def test_rows_gemm_against_f32_reference(M, N, K, silu):
     """skv_linear_rows_bf16 (M <= 32 token rows on the MFMA N dimension; two 16-token tiles per weight fragment from
     M = 17, the reference's published batch is 24: test/e2e.py:63-68) against an f32 matmul of the same bf16

@@ -286,15 +286,18 @@ def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None):
     return cache, cs, g
 
 
-@pytest.mark.parametrize("kv_heads,glm,hit", [(8, False, 0.67), (8, False, 0.0), (8, False, 1.0), (4, False, 0.67),
-                                              (4, True, 0.0), (4, True, 0.67)])
-def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm, hit):
+@pytest.mark.parametrize("kv_heads,glm,hit,ctx", [(8, False, 0.67, 8192), (8, False, 0.0, 8192), (8, False, 1.0, 8192),
+                                                  (4, False, 0.67, 8192), (4, True, 0.0, 8192), (4, True, 0.67, 8192),
+                                                  # BASELINE.json configs 2 and 3 at their full per-layer size
+                                                  (8, False, 0.67, 131072), (4, True, 0.67, 204800)])
+def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm, hit, ctx):
     """The path the headline number runs on (bench.py defaults: in-place layout, attention over the resident rows inside
     the fetch launch, finish kernel over the miss rows) at the headline shape: S = 256 chunks, sparse region [448, 2496),
-    kv_len = 2,499, G = 4 and G = 8, chunk hit rates 0 / 0.67 / 1.  Checked against the oracle: selected set bit-exact,
+    kv_len = 2,499, G = 4 and G = 8, chunk hit rates 0 / 0.67 / 1; also one layer of the 131,072-token Llama-3-1048K and of
+    the 204,800-token GLM-4 configuration (BASELINE.json configs 2 and 3) at full size.  Checked against the oracle: selected set bit-exact,
     V rows byte-exact against the host table, K rows within the one-ulp-flip bound of the oracle's rebuild, and the
     attention output against the oracle's F32 result over the device's K / V bytes at 1e-3 |ref| + half a bf16 ulp."""
-    cache, cs, g = _headline_cache(kv_heads, glm)
+    cache, cs, g = _headline_cache(kv_heads, glm, L=ctx)
     Hq, D, C, S = 32, 128, 8, cache.select_sets
     Gq = Hq // kv_heads
     assert S == 256 and cache.sparse_start == 448 and cache.sparse_end == 2496 and cache.k_cache_buffer.shape[-2] == 2592
