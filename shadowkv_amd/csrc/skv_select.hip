@@ -820,8 +820,13 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         is_gt = age > thr_age ? 1 : 0;
         is_eq = age == thr_age ? 1 : 0;
     }
-    int ev_pk;   // (rows 48..79 of s_w: the wave maxima of the threshold search are dead)
-    const int hm = block_scan_incl2(is_hit_slot | (is_miss << 16), is_gt | (is_eq << 16), s_w + 48, tid, ev_pk);
+    int ev_pk, hm;   // (rows 48..79 of s_w: the wave maxima of the threshold search are dead)
+    if (lru) {
+        hm = block_scan_incl2(is_hit_slot | (is_miss << 16), is_gt | (is_eq << 16), s_w + 48, tid, ev_pk);
+    } else {         // every slot that is not a hit is refilled: its rank follows from the hit prefix, one scan
+        hm = block_scan_incl1(is_hit_slot | (is_miss << 16), s_w + 48, tid);
+        ev_pk = tid + 1 - (hm & 0xffff);                   // inclusive count of non-hit slots up to tid (tid < R)
+    }
     const int hit_incl = hm & 0xffff, miss_incl = hm >> 16;
     if (tid == T2_THREADS - 1) {
         s_out[4] = hit_incl;

@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-extras --no-cpu-baseline "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_prof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-extras --no-cpu-baseline "$@" > gpurun_out/${tag}_prof_bench.json 2> gpurun_out/${tag}_prof.log
 f=$(find $out -name '*kernel_stats.csv' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --no-cpu-baseline $*"; python3 tools/summarize_rocprof.py "$f" 45; echo "# bench line under the profiler:"; cat gpurun_out/${tag}_bench.json; } > gpurun_out/${tag}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras --no-cpu-baseline $*"; python3 tools/summarize_rocprof.py "$f" 45; echo "# bench line under the profiler:"; cat gpurun_out/${tag}_prof_bench.json; } > gpurun_out/${tag}_kernel_stats.txt
 grep -E "skv_|^# total" gpurun_out/${tag}_kernel_stats.txt
