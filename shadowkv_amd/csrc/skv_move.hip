@@ -46,10 +46,10 @@ __global__ __launch_bounds__(256) void skv_gather_rows_kernel(const u32x4* __res
 // Two-phase movement used by the fused decode path (no in-kernel synchronisation at all):
 //   phase 1  skv_stage_hits_kernel : temp[b][i] <- buf[b][sparse + offsets[i]]   for hit rows that move
 //   phase 2  skv_land_rows_kernel  : buf[b][sparse + i] <- temp[b][i] (moved hits), <- host[offsets[i]] (misses)
-// The kernel boundary orders "every read of the old layout" before "any write of the new one".  Measured
-// reason for not using the single-kernel team counter here: while the V launch is pulling its miss rows
-// over PCIe, agent-scope atomics / sc1 polls of a concurrently running K compaction are served only when
-// the PCIe reads drain (the K launch always ended with the V launch, 37 us instead of 15 us alone).
+// The kernel boundary orders "every read of the old layout" before "any write of the new one".  A single-kernel
+// variant with an inter-workgroup counter (round 1) was removed: nothing in this library spins on another workgroup,
+// and while a V launch pulls its miss rows over PCIe, agent-scope atomics / polls of a concurrent K compaction were
+// served only when the PCIe reads drained (measured 37 us instead of 15 us alone).
 // Costs one extra HBM round trip for the moved hit rows (<= 2 x 4 MB per layer), saves every spin.
 // grid (ceil(S/8), B, nbuf): z selects the buffer (0 = K, 1 = V).
 // ---------------------------------------------------------------------------------------------------

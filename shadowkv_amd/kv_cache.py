@@ -5,14 +5,15 @@ methods launch the hand-written gfx950 kernels of libshadowkv_hip.so.
 
 State (per layer l, batch b, KV head h; D = head_dim, C = chunk_size, S = sparse_budget // C):
   v_cache_cpu   pinned host  [L, bs, kv, max_length // C, C*D]   every V chunk, 2 KiB rows (C=8, D=128)
-  k_/v_cache_buffer  HBM     [L, bs, kv, buf_len, D],  buf_len = budget + 128 + (outlier + local)*C
+  k_/v_cache_buffer  HBM     [L, bs, kv, buf_len, D],  buf_len = R*C + 128 + (outlier + local)*C
         rows [0, prefill_local)            last tokens of the prompt (exact K / V)
         rows [prefill_local, sparse_start) outlier chunks (exact K / V)
-        rows [sparse_start, sparse_end)    the S selected chunks; slot i holds chunk position_ids[l,b,h,i]
+        rows [sparse_start, sparse_end)    R chunk slots; slot i holds chunk position_ids[l,b,h,i] (R = S: the S selected
+                                           chunks, the reference's layout; resident_sets = R > S: see __init__)
         rows [sparse_end, buf_len)         tokens generated so far
   U [L, bs, seq, r], SV [L, bs, kv, D, r]   rank-r factorisation of the pre-RoPE keys (r-contiguous)
   k_landmark [L, bs, kv, N, D], k_landmark_idx int64 [L, bs, kv, N]   chunk means + their chunk ids
-  position_ids int64 [L, bs, kv, S], offsets int32 [bs*kv*S], cnts int32 [bs*kv], signals int32 [bs*kv]
+  position_ids int64 [L, bs, kv, R], offsets int32 [bs*kv*S], cnts int32 [bs*kv], signals int32 [bs*kv]
 
 MI355X-first differences that do not change results:
   * U / SV / landmarks are created in HBM straight away (288 GB): H2D() only sizes the decode
@@ -29,6 +30,8 @@ Beyond the reference's surface (opt-in, used by DecoderLM.forward_fused / bench.
   * select_fetch_inplace / select_fetch_attend_inplace: the same decode step with an in-place resident set (chunks
     selected again keep their slot, misses take the freed slots) and, optionally, the attention over the resident rows
     inside the PCIe-bound fetch launch - same chunk set, K / V bytes and attention values (up to summation order).
+  * resident_sets > select_sets: more chunk slots stay resident than are attended (least-recently-selected
+    replacement, in-place layout only) - same selections and outputs, fewer chunks over PCIe.
   * v_offload=False keeps the chunked V table in HBM; svd_mode="gram" factorises through K^T K;
     prefill_kv_cache computes chunk means / outlier scores in one native pass when the keys are on the GPU.
 """
@@ -525,8 +528,9 @@ class ShadowKVCache_CPU:
     def select_fetch_attend_inplace(self, layer_idx, query_states, cos_sin_cache, kv_len=0, kv_len_dev=None):
         """select_fetch_inplace + sparse attention of one layer with the attention over the already-resident rows
         (local, outliers, surviving chunks, generated tokens) running INSIDE the fetch launch, on the CUs the PCIe-bound
-        V fetch leaves idle; the miss rows are attended by a second, small launch that also merges everything.
-        4 launches + 1 (score, normalize, top-k/diff, rebuild||fetch||attention, finish).  Returns [bs, 1, Hq, D]
+        V fetch leaves idle; every miss tile (8 chunks) is attended by the workgroup that rebuilds its K rows and lands
+        its V rows, straight from LDS / the landing registers; a small second launch merges the records.
+        4 launches + 1 (score, normalize, top-k/diff, rebuild||fetch||attention, merge).  Returns [bs, 1, Hq, D]
         like tensor_op.sparse_attention_decode; same values up to the order of the f32 sums."""
         if query_states.shape[-2] != 1:
             raise ValueError("decode-time selection expects q_len == 1")

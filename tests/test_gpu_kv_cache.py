@@ -218,8 +218,8 @@ def test_v_table_in_hbm_gives_the_same_cache_bytes():
 
 @pytest.mark.parametrize("case", ["llama_cpu_b1024", "glm_small"])
 def test_overlapped_attention_equals_fetch_then_attend(case):
-    """select_fetch_attend_inplace (attention over the resident rows inside the fetch launch + finish kernel over the
-    miss rows) against select_fetch_inplace + sparse_attention_decode from the same state, several steps: identical
+    """select_fetch_attend_inplace (attention over the resident rows inside the fetch launch, the miss tiles attended by
+    the workgroups that build them, merge kernel) against select_fetch_inplace + sparse_attention_decode from the same state, several steps: identical
     cache bytes / ids, attention outputs equal up to the order of the f32 sums, and both within the oracle's f64
     attention tolerance."""
     from shadowkv_amd import tensor_op
@@ -292,7 +292,7 @@ def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None):
                                                   (8, False, 0.67, 131072), (4, True, 0.67, 204800)])
 def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm, hit, ctx):
     """The path the headline number runs on (bench.py defaults: in-place layout, attention over the resident rows inside
-    the fetch launch, finish kernel over the miss rows) at the headline shape: S = 256 chunks, sparse region [448, 2496),
+    the fetch launch, miss tiles attended where they are built, merge kernel) at the headline shape: S = 256 chunks, sparse region [448, 2496),
     kv_len = 2,499, G = 4 and G = 8, chunk hit rates 0 / 0.67 / 1; also one layer of the 131,072-token Llama-3-1048K and of
     the 204,800-token GLM-4 configuration (BASELINE.json configs 2 and 3) at full size.  Checked against the oracle: selected set bit-exact,
     V rows byte-exact against the host table, K rows within the one-ulp-flip bound of the oracle's rebuild, and the
