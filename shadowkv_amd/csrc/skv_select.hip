@@ -32,17 +32,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef SKV_SCORE_WAVES
 #define SKV_SCORE_WAVES 16                      // waves per 256-landmark tile (16 rows each; 4/8/16 measured: 9.3 / 8.8 / 8.5 us)
 #endif
-#define SKV_SCORE_ITERS (64 / SKV_SCORE_WAVES)   // 4-row wave-instructions per wave
 // ABL (ablation, diagnostic builds only - tools/score_probe.hip): 0 = the kernel; 1 = loads only (no dot
 // products); 2 = no per-tile statistics tail.  The library instantiates ABL = 0 only.
-template <int G, int ABL = 0>
-__global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
+// WAVES per tile: 16 (measured best for G <= 4: 4 / 8 / 16 waves 9.3 / 8.8 / 8.5 us); G = 8 (GLM) takes 8: its q fragment
+// alone is 64 VGPRs, 100 in all - with 16 waves per workgroup only ONE workgroup fits a CU and the 400 workgroups of the
+// 200K configuration ran in two rounds (12.0 us for 26 MB); 8 waves of ~120 VGPRs fit twice, all 400 are resident at once.
+template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES)>
+__global__ __launch_bounds__(64 * WAVES) void skv_score_tile_kernel(
     const bf16_t* __restrict__ q,    // [B][G][128]
     const bf16_t* __restrict__ lm,   // [B][N][128]
     bf16_t* __restrict__ D,          // [B][G][N]
     float* __restrict__ part_max,    // [B][T][G]
     float* __restrict__ part_sum,    // [B][T][G]
     int N, int T, float alpha) {
+    constexpr int ITERS = 64 / WAVES;               // 4-row wave-instructions per wave
     const int b = blockIdx.y, t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, rsel = lane >> 4;
@@ -62,10 +65,10 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
         }
     }
 
-    const int row0 = t * SKV_TILE + wave * (4 * SKV_SCORE_ITERS) + rsel;
-    u32x4 x[SKV_SCORE_ITERS];
+    const int row0 = t * SKV_TILE + wave * (4 * ITERS) + rsel;
+    u32x4 x[ITERS];
 #pragma unroll
-    for (int i = 0; i < SKV_SCORE_ITERS; ++i) {
+    for (int i = 0; i < ITERS; ++i) {
         int row = row0 + i * 4;
         row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
         x[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub));
@@ -75,12 +78,12 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
     if (ABL == 1) {   // memory stream only: fold the loaded words so the loads stay, skip all arithmetic
         uint32_t f = 0;
 #pragma unroll
-        for (int i = 0; i < SKV_SCORE_ITERS; ++i) f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+        for (int i = 0; i < ITERS; ++i) f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
         if (f == 0x12345u) D[0] = (bf16_t)f;
         return;
     }
 #pragma unroll
-    for (int i = 0; i < SKV_SCORE_ITERS; ++i) {
+    for (int i = 0; i < ITERS; ++i) {
         float xf[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
 #pragma unroll
         for (int g = 0; g < G; ++g) part[g] = (g & 1) ? acc2[g / 2].y : acc2[g / 2].x;
         const float tot = row16_tree_sum_transposed<G>(part, lane);
-        if (publish) sD[my_g][wave * (4 * SKV_SCORE_ITERS) + i * 4 + rsel] = f2bf(alpha * tot);
+        if (publish) sD[my_g][wave * (4 * ITERS) + i * 4 + rsel] = f2bf(alpha * tot);
     }
     __syncthreads();
     if (ABL == 2) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * SKV_SCORE_WAVES) void skv_score_tile_kernel(
     // per-tile statistics: wave w owns query head g = w (+ k*waves) and all 256 columns of the tile, 4 consecutive
     // columns per lane, so max, integer exp-sum and the logit store need no cross-wave step and no further barrier
     // (ablation, tools/score_probe.hip: the previous column-per-thread tail cost 3.5 of 11.5 us).
-    for (int g = wave; g < G; g += SKV_SCORE_WAVES) {
+    for (int g = wave; g < G; g += WAVES) {
         const int c0 = 4 * lane;
         float dv[4];
         float mloc = -INFINITY;
@@ -899,7 +902,7 @@ static inline int next_pow2(int v) {
 template <int G>
 static int launch_score_g(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int N, int T,
                           float alpha, hipStream_t st) {
-    hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(64 * SKV_SCORE_WAVES), 0, st, (const bf16_t*)q,
+    hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(64 * (G == 8 ? 8 : SKV_SCORE_WAVES)), 0, st, (const bf16_t*)q,
                        (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha);
     return SKV_OK;
 }
