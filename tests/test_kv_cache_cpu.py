@@ -144,3 +144,42 @@ def test_decode_methods_fail_loudly_without_gpu(built):
         pytest.skip("GPU present")
     with pytest.raises(Exception):
         cache.get_retrieval_position_ids(0, inp["q_steps"][0])
+
+
+def test_resident_set_option_lays_out_the_buffers_and_keeps_the_reference_state():
+    """resident_sets > select_sets (host logic only): the sparse region grows to resident_sets chunks with the generated rows
+    behind it, the first select_sets slots hold exactly what the default cache holds (same ids, same K / V rows), the extra
+    slots start empty; the reference-shaped decode methods refuse the option; bad sizes are rejected."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    case = "llama_small"
+    c, inp = G.CASES[case], G.make_inputs(case)
+    k_roped = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+    caches = []
+    for R in (None, 3 * (c["budget"] // c["chunk"])):
+        cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                                  sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], resident_sets=R)
+        cache.get_svd(inp["k_pre"], 0)
+        cache.prefill_kv_cache(inp["v"], 0, k_roped, inp["q_last"])
+        caches.append(cache)
+    ref, big = caches
+    S, C = ref.select_sets, ref.chunk_size
+    assert ref.resident_sets == S and ref.attend_slot_args() == {}
+    assert big.resident_sets == 3 * S and big.position_ids.shape[-1] == 3 * S and big._slot_age.shape == (1, big.block_num, 3 * S)
+    assert big.sparse_start == ref.sparse_start and big.sparse_end == ref.sparse_end + 2 * S * C
+    assert big.k_cache_buffer.shape[-2] == ref.k_cache_buffer.shape[-2] + 2 * S * C
+    assert big.generated_row_slack() == ref.generated_row_slack()
+    assert torch.equal(big.position_ids[..., :S], ref.position_ids) and bool((big.position_ids[..., S:] == -1).all())
+    lo, hi = ref.sparse_start, ref.sparse_start + S * C
+    for a, b in ((big.k_cache_buffer, ref.k_cache_buffer), (big.v_cache_buffer, ref.v_cache_buffer)):
+        assert torch.equal(a[..., :hi, :].view(torch.int16), b[..., :hi, :].view(torch.int16))
+        assert lo < hi
+    args = big.attend_slot_args()
+    assert args["select_sets"] == S and args["resident_sets"] == 3 * S and args["sparse_start"] == big.sparse_start
+    with pytest.raises(RuntimeError, match="resident_sets == select_sets"):
+        big.get_retrieval_position_ids(0, inp["q_last"][:, :, -1:])
+    with pytest.raises(RuntimeError, match="resident_sets == select_sets"):
+        big.get_value_cache(0, big.position_ids[0])
+    for bad in (S - 1, 1025):
+        with pytest.raises(ValueError):
+            ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], resident_sets=bad)
