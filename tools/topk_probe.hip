@@ -10,7 +10,8 @@
 int main(int argc, char** argv) {
     const bool inplace = argc > 1 && !strcmp(argv[1], "inplace");
     const int B = 8, N = 15560, S = 256, stride = (N + 7) & ~7;
-    const int R = argc > 6 ? atoi(argv[6]) : S;     // argv[6]: resident slots per head (> S: least-recently-selected replacement)
+    const int R = argc > 6 ? atoi(argv[6]) : S;
+    const bool nolm = getenv("TOPK_PROBE_NOLM") != nullptr;   // identity slot -> id map: no id gathers at all     // argv[6]: resident slots per head (> S: least-recently-selected replacement)
     std::vector<uint16_t> sc((size_t)B * stride);
     std::vector<int64_t> lm((size_t)B * N), cached((size_t)B * R);
     srand(3);
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
             skv_launch_topk_reorder(dsc2, stride, dlm2, nullptr, dc2, doff2, dcnt2, nullptr, nullptr, B, N, S, 0);
             hipDeviceSynchronize();
         }
-        int rc = skv_launch_topk_resident(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
+        int rc = skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
         hipDeviceSynchronize();
 #ifdef SKV_TOPK_STAMPS
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
@@ -82,7 +83,7 @@ int main(int argc, char** argv) {
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int it = 0; it < 50; ++it) skv_launch_topk_resident(dsc, stride, dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
+    for (int it = 0; it < 50; ++it) skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("back-to-back launches: %.2f us per launch (event time, includes launch boundary)\n", ms * 1e3 / 50);
