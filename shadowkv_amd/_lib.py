@@ -77,6 +77,11 @@ def lib():
             raise ShadowKVNativeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run __graft_entry__.build() or `make -C shadowkv_amd/csrc`). There is no CPU fallback.")
+        # torch first: PyTorch-ROCm ships its own HIP runtime (libamdhip64 in torch/lib) and every stream / tensor this
+        # library is handed comes from it.  Loaded the other way round, this library pulls in /opt/rocm's runtime first and
+        # the process ends up with kernels registered in one runtime and streams from the other (observed: the first launch
+        # that needs hipFuncSetAttribute fails).  With torch loaded, the NEEDED libamdhip64 resolves to the one already there.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
