@@ -735,7 +735,53 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         const int pincl = block_scan_incl1(packed, s_w + 32, tid);                    // barrier (E)
         const int pexcl = pincl - packed;
         TOPK_STAMP(4);
-        {
+        // A thread walks its candidates one by one, ~160 ns each (in-kernel stamps): fine for the one or two it has when the
+        // selection is scattered - but hot chunks come in runs, a thread that owns a run has up to 16, and the whole workgroup
+        // waits for it (+2-3 us).  A wave that holds such a thread and few enough candidates in all lets its LANES take one
+        // candidate each instead: owners mark where their candidates start (LDS, the dead score histogram), a max-scan hands
+        // every lane its owner, the owner's masks / prefixes come over with shuffles, and the lane places "its" candidate with
+        // the same position formula as the walk below.
+        const int cge = NG == 1 ? __builtin_popcount(mge[0]) : 0;
+        int rounds = 0, cincl = 0;
+        if (NG == 1 && __any(cge >= 4)) {                       // (uniform per wave)
+            cincl = wave_scan_incl(cge);
+            const int wtot = __builtin_amdgcn_readlane(cincl, 63), maxc = wave_max_i32_dpp(cge);
+            // a round of 64 candidates costs about as much as three steps of the walk: worth it up to maxc / 4 rounds
+            if (wtot <= 64 * min(maxc / 4, 4)) rounds = (wtot + 63) / 64;
+        }
+        if (rounds > 0) {
+            const int lane = tid & 63, cexcl = cincl - cge, wtot = __builtin_amdgcn_readlane(cincl, 63);
+            volatile int* sw = s_hist + 64 + (tid >> 6) * 64;   // this wave's marks (LDS operations of one wave execute in order)
+            for (int r = 0; r < rounds; ++r) {
+                const int base = 64 * r;                        // this round places candidates base .. base + 63 of the wave
+                sw[lane] = 0;
+                if (cge > 0 && cexcl >= base && cexcl < base + 64) sw[cexcl - base] = lane + 1;
+                if (cexcl < base && cincl > base) sw[0] = lane + 1;          // the owner whose candidates straddle the round start
+                const int own = wave_scan_max(sw[lane]) - 1;    // the lane that owns candidate base + `lane`
+                const int src = own < 0 ? 0 : own;
+                const uint32_t o_ge = (uint32_t)__shfl((int)mge[0], src, 64), o_gt = (uint32_t)__shfl((int)mgt[0], src, 64);
+                const int o_pexcl = __shfl(pexcl, src, 64), o_cexcl = __shfl(cexcl, src, 64);
+                const int o_id0l = __shfl((int)(id0 & 0xffffffffll), src, 64), o_id0h = __shfl((int)(id0 >> 32), src, 64);
+                const int o_id1l = __shfl((int)(id1 & 0xffffffffll), src, 64), o_id1h = __shfl((int)(id1 >> 32), src, 64);
+                if (base + lane < wtot) {
+                    const int ord = base + lane - o_cexcl;                         // which of the owner's candidates
+                    const int e = kth_set_bit(o_ge, ord);
+                    const uint32_t below = (1u << e) - 1u, o_eq = o_ge & ~o_gt;
+                    const int gt_run = (o_pexcl & 1023) + __builtin_popcount(o_gt & below);
+                    const int eq_run = (o_pexcl >> 10) + __builtin_popcount(o_eq & below);
+                    const int j = ((tid & ~63) + src) * (SEGV * 8) + e;
+                    int pos = -1;
+                    if ((o_gt >> e) & 1u) pos = gt_run + min(eq_run, need_eq);
+                    else if (eq_run < need_eq) pos = gt_run + eq_run;
+                    if (pos >= 0) {
+                        const long long i0 = ((long long)o_id0h << 32) | (unsigned int)o_id0l;
+                        const long long i1 = ((long long)o_id1h << 32) | (unsigned int)o_id1l;
+                        s_cur[pos] = j;
+                        s_id[pos] = lm_idx == nullptr ? (long long)j : ord == 0 ? i0 : ord == 1 ? i1 : -1ll;
+                    }
+                }
+            }
+        } else {
             int gt_run = pexcl & 1023, eq_run = pexcl >> 10, ord = 0;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {

@@ -71,6 +71,32 @@ __device__ __forceinline__ int block_scan_incl1(int v, int* s_w, int tid) {
     return v + pre;
 }
 
+// inclusive MAX scan over the wave (values >= 0), same DPP ladder as wave_scan_incl
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// position of the k-th (0-based) set bit of m, k < popcount(m): five halvings
+__device__ __forceinline__ int kth_set_bit(uint32_t m, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const uint32_t low = m & ((1u << w) - 1u);
+        const int c = __builtin_popcount(low);
+        const bool up = k >= c;
+        k -= up ? c : 0;
+        m = up ? m >> w : low;
+        pos += up ? w : 0;
+    }
+    return pos;
+}
+
 // two inclusive scans behind ONE barrier (s_w: two rows of 16); returns the first, the second through v2_incl
 __device__ __forceinline__ int block_scan_incl2(int v1, int v2, int* s_w, int tid, int& v2_incl) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -201,6 +201,9 @@ def test_topk_stage_pinned_to_reference_scores(case):
     (1, 40000, 512, "seg8"),       # 8 vectors per thread
     (1, 131056, 256, "seg16"),     # 16 vectors per thread (1M-token context)
     (2, 300, 32, "zeros"),         # fewer non-zero scores than S: zeros tie at the k-th value
+    (4, 15560, 256, "runs"),       # the top scores in runs of consecutive slots (attention locality): one thread owns up to 16
+    (4, 15560, 256, "runs_tied"),  # ... with the k-th value tied inside the runs
+    (2, 30000, 256, "runs"),       # 4 vectors (32 keys) per thread
 ])
 def test_select_from_scores_edge_cases(blocks, N, S, kind):
     g = torch.Generator().manual_seed(N + S)
@@ -215,6 +218,18 @@ def test_select_from_scores_edge_cases(blocks, N, S, kind):
     elif kind == "steps":
         x = torch.tensor([1e-3, 3e-4, 1e-4, 6e-5])[torch.randint(0, 4, (blocks, N), generator=g)]
         x[:, ::97] = 0.02
+    elif kind in ("runs", "runs_tied"):
+        x = torch.softmax(torch.randn(blocks, N, generator=g) * 1.0, dim=-1) * 1e-2
+        for bb in range(blocks):
+            left = S + 7                                   # a little more than S high scores: the k-th value falls inside a run
+            while left > 0:
+                n = int(torch.randint(3, 33, (1,), generator=g))
+                st = int(torch.randint(0, N - n, (1,), generator=g))
+                vals = torch.rand(n, generator=g) * 0.5 + 0.5
+                if kind == "runs_tied":
+                    vals = torch.full((n,), 0.75)
+                x[bb, st:st + n] = vals
+                left -= n
     elif kind == "zeros":
         x = torch.zeros(blocks, N)
         x[:, ::29] = torch.rand(blocks, len(range(0, N, 29)), generator=g)
