@@ -32,9 +32,12 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     // never past the rows a head owns (the reference's view slice [:sparse_end + gen] clamps the same way)
     const int kv_len = min(kv_len_dev ? *kv_len_dev : kv_len_host, kv_rows);
-    skv_attn_partial_body<G, LISTED>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
-                                     LISTED ? slots + (size_t)blockIdx.y * n_slots : nullptr, n_slots, sparse_start,
-                                     resident_rows);
+    if constexpr (G == 8 && !LISTED)      // Q.K^T on v_mfma_f32_16x16x32_bf16 (10-11 % faster at G = 8, a tie at G = 4)
+        skv_attn_partial_body_mfma<G>(q, k, v, ws, kv_len, kv_stride_h, splits, blockIdx.x, blockIdx.y, scale, s_dyn);
+    else
+        skv_attn_partial_body<G, LISTED>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
+                                         LISTED ? slots + (size_t)blockIdx.y * n_slots : nullptr, n_slots, sparse_start,
+                                         resident_rows);
 }
 
 __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
@@ -136,7 +139,8 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         return SKV_ERR_ARG;
     const int G = Hq / Hkv;
     dim3 grid(splits, bs * Hkv), block(256);
-    const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float) + (slots ? (size_t)n_slots * sizeof(int) : 0);
+    const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float) + (slots ? (size_t)n_slots * sizeof(int) : 0) +
+                        (G == 8 && !slots ? SKV_ATTN_MFMA_LDS_FLOATS * sizeof(float) : 0);
 #define SKV_AT_L(GG, LL)                                                                                        \
     do {                                                                                                        \
         static size_t attr_bytes = 0;                                                                           \

@@ -152,3 +152,112 @@ __device__ __forceinline__ void skv_attn_partial_body(
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with Q.K^T on the matrix pipe, used for G = 8 (GLM-4: twice the per-key VALU work of G = 4).  Measured
+// against the body above on the same data, grid and records (tools/attn_mfma_probe.hip, profiles/r02_attn_mfma_probe.txt):
+// G = 8: 7.97 vs 9.00 us (32 splits), 6.67 vs 7.43 us (64 splits); G = 4: 6.95 vs 6.99 us - a tie, the VALU body stays there.
+// P.V stays on the VALU: the MFMA A operand of a P.V product needs the keys on the fragment's k index while the scores come
+// out with the keys on rows of the C tile; with G <= 8 useful rows of 16 the reshuffle costs more than the 8 FMAs it replaces.
+// Needs 4 x 16 x 17 floats of LDS behind the group partials (SKV_ATTN_MFMA_LDS_FLOATS).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 at_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float at_f32x4;
+#define SKV_ATTN_MFMA_LDS_FLOATS (4 * 16 * 17)
+// MFMA scores: a wave takes 16 keys per step.  A = K rows (lane (r = l & 15, c = l >> 4) loads K[key r][32 ks + 8 c ..+8],
+// 4 k-steps), B = Q^T from registers (column g = l & 15, zero for g >= G), C[key (l >> 4) * 4 + i][g = l & 15].
+// The scores go through LDS ([key][g]) so that the 16-lane group that owns a V row finds its G weights; the rest (online
+// softmax per group, p * V, group merge, record) is the shipped body's.
+template <int G>
+__device__ __forceinline__ void skv_attn_partial_body_mfma(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, float* __restrict__ ws, int kv_len,
+                                                           long long stride_h, int splits, int split, int bh, float scale,
+                                                           float* s_dyn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp4 = lane >> 4;
+    const int per = (kv_len + splits - 1) / splits, k0 = split * per, k1 = min(k0 + per, kv_len);
+    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);
+    float* s_sc = s_dyn + AT_GROUPS * G * (AT_D + 2) + wave * 16 * 17;     // per wave [16 keys][16 g] (+1 pad)
+    // B fragments: q_g[32 ks + 8 c + j] * scale for g = sub < G
+    at_bf16x8 bq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (sub < G) w = *reinterpret_cast<const u32x4*>(q + ((size_t)bh * G + sub) * AT_D + 32 * ks + 8 * grp4);
+        bq[ks] = __builtin_bit_cast(at_bf16x8, w);
+    }
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+    const bf16_t* kb = k + (size_t)bh * stride_h;
+    const bf16_t* vb = v + (size_t)bh * stride_h + 8 * sub;
+    for (int key0 = k0 + wave * 16; key0 < k1; key0 += 64) {       // 4 waves x 16 keys per step
+        // A fragments + the V rows of this wave's 16 keys (4 rows per 16-lane group: keys key0 + grp4 + 4 i)
+        const int kr = min(key0 + sub, k1 - 1);
+        u32x4 ak[4], vr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ak[ks] = *reinterpret_cast<const u32x4*>(kb + (size_t)kr * AT_D + 32 * ks + 8 * grp4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)min(key0 + grp4 + 4 * i, k1 - 1) * AT_D);
+        at_f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, ak[ks]), bq[ks], c, 0, 0, 0);
+        // C[key grp4 * 4 + i][g = sub] -> LDS [key][g]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_sc[(grp4 * 4 + i) * 17 + sub] = c[i] * scale;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): wave-local LDS hand-over
+        float sc[4][G];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = grp4 + 4 * i;
+#pragma unroll
+            for (int g = 0; g < G; ++g) sc[i][g] = (key0 + key < k1) ? s_sc[key * 17 + g] : -INFINITY;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float mn = m[g];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mn = fmaxf(mn, sc[i][g]);
+            const float corr = (mn == -INFINITY) ? 1.f : __expf(m[g] - mn);
+            float lsum = l[g] * corr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = (sc[i][g] == -INFINITY) ? 0.f : __expf(sc[i][g] - mn);
+                lsum += p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[g][2 * j] = __builtin_fmaf(p, bf_lo(vr[i][j]), acc[g][2 * j]);
+                    acc[g][2 * j + 1] = __builtin_fmaf(p, bf_hi(vr[i][j]), acc[g][2 * j + 1]);
+                }
+            }
+            l[g] = lsum; m[g] = mn;
+        }
+    }
+    const int grp = wave * 4 + grp4;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[g][j];
+        if (sub == 0) { s_part[grp][g][AT_D] = m[g]; s_part[grp][g][AT_D + 1] = l[g]; }
+    }
+    __syncthreads();
+    for (int o = tid; o < G * AT_D; o += 256) {
+        const int g = o / AT_D, d = o % AT_D;
+        float M = -INFINITY;
+        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
+        float a = 0.f, L = 0.f;
+        for (int r = 0; r < AT_GROUPS; ++r) {
+            const float mr = s_part[r][g][AT_D], w = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+            a = __builtin_fmaf(s_part[r][g][d], w, a);
+            L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
+        }
+        float* dst = ws + (((size_t)bh * G + g) * splits + split) * AT_REC;
+        dst[d] = a;
+        if (d == 0) { dst[AT_D] = M; dst[AT_D + 1] = L; }
+    }
+}
