@@ -51,13 +51,18 @@ def test_graph_equals_eager(use_walk, layout):
 
 
 @pytest.mark.parametrize("glm", [False, True])
-def test_fused_step_close_to_reference_call_order(glm):
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_fused_step_close_to_reference_call_order(glm, seed):
     """forward_fused (fused small ops, device-side scalars) against the reference-shaped call order
-    (inference -> layer_compute -> update_kv_cache / get_* methods, torch ops for norm / RoPE / SiLU).  The
-    dense side differs only by op fusion (one rounding more or less per op), so logits must agree closely
-    and the chunk selection of the first layer must be identical."""
-    m1, llama = _make(glm=glm)
-    m2, _ = _make(glm=glm)
+    (inference -> layer_compute -> update_kv_cache / get_* methods, torch ops for norm / RoPE / SiLU).
+    (1) Free running: the new K / V rows of layer 0 agree to bf16 rounding (same rotation arithmetic; the QKV projection
+    differs in f32 accumulation order: native GEMV vs hipBLASLt).  The chunk selection of this tiny random model is a
+    near-tie everywhere (32 of 576 chunks, flat scores): one flipped bf16 bit in q moves a few ids across the boundary, after
+    which the layers see different chunks - so logits are only compared when every layer selected the same set.
+    (2) With the same query table in both paths (selection inputs identical): every layer must select the same set and
+    the logits must agree to the dense side's rounding differences (one rounding more or less per fused op)."""
+    m1, llama = _make(glm=glm, seed=seed)
+    m2, _ = _make(glm=glm, seed=seed)
     tok = torch.tensor([[23]], device=DEV)
     c1, c2 = m1.kv_cache, m2.kv_cache
     pos = m1.get_ctx(tok)
@@ -67,12 +72,28 @@ def test_fused_step_close_to_reference_call_order(glm):
     c2.note_kv_appended(1)
     torch.cuda.synchronize()
     assert c1.kv_offset == c2.kv_offset and c1.gen_offset == c2.gen_offset
-    # new K/V rows of layer 0 (RoPE'd k, raw v): same rotation arithmetic, the QKV projection differs only in
-    # f32 accumulation order (native GEMV vs hipBLASLt)
     assert torch.allclose(c1.k_cache_buffer[0][:, :, row].float(), c2.k_cache_buffer[0][:, :, row].float(), rtol=0.02, atol=0.02)
     assert torch.allclose(c1.v_cache_buffer[0][:, :, row].float(), c2.v_cache_buffer[0][:, :, row].float(), rtol=0.02, atol=0.02)
+    s1, s2 = c1.position_ids.sort(dim=-1).values, c2.position_ids.sort(dim=-1).values
+    overlap0 = float((s1[0].unsqueeze(-1) == s2[0].unsqueeze(-2)).any(-1).float().mean())
+    assert overlap0 >= 0.6, overlap0                       # layer 0: the same selection up to boundary flips
+    if torch.equal(s1, s2):
+        rel = (la - lb).abs().max() / la.abs().max()
+        assert float(rel) < 0.02, float(rel)
+    # (2) identical selection inputs
+    m1, _ = _make(glm=glm, seed=seed)
+    m2, _ = _make(glm=glm, seed=seed)
+    c1, c2 = m1.kv_cache, m2.kv_cache
+    walk = llama.QueryWalk(m1, step=0.3, seed=3)
+    walk.advance()
+    m1.query_hook = walk
+    la = m1.inference(tok, pos)
+    lb = m2.forward_fused(tok, pos, torch.tensor([row], device=DEV), kv_len=row + 1, q_table=walk.qb)
+    torch.cuda.synchronize()
+    assert torch.equal(c1.position_ids.sort(dim=-1).values, c2.position_ids.sort(dim=-1).values)
+    assert torch.equal(c1._cnts_layers, c2._cnts_layers)
     rel = (la - lb).abs().max() / la.abs().max()
-    assert float(rel) < 0.05, float(rel)
+    assert float(rel) < 0.02, float(rel)
 
 
 def test_fused_small_ops_against_torch():
