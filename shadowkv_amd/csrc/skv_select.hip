@@ -224,12 +224,52 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
     }
     // every workgroup recomputes the finals from the T partials (no cross-workgroup hand-off); long contexts give a
     // workgroup several tiles so that this stays a small fraction of its work (tiles_per_block, chosen by the launcher)
-    for (int g = wave; g < G; g += 4) {
-        float mx, inv;
-        softmax_finalize_wave(part_max + (size_t)b * T * G + g, part_sum + (size_t)b * T * G + g, T, G, lane, mx, inv);
-        if (lane == 0) {
-            s_m[g] = mx;
-            s_inv[g] = inv;
+    constexpr int GW = (G + 3) / 4;     // query heads per wave
+    if (T > 64 && T <= 256) {
+        // 65..256 tiles (GLM-4 at 200K: 100): the generic routine below makes two dependent passes over the partials per head
+        // and a wave owns GW heads one after the other - up to 4 memory round trips on the critical path of a 7 us kernel.
+        // Here every partial a wave needs (<= 4 per lane and head) is requested up front, then reduced in the SAME order
+        // (maximum first; sum over tiles lane, lane + 64, ... in that order; the contract's reduction tree).
+        float pmv[GW][4], psv[GW][4];
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int g = wave + 4 * k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tt = lane + 64 * i;
+                const bool in = g < G && tt < T;
+                pmv[k][i] = in ? part_max[((size_t)b * T + tt) * G + g] : -INFINITY;
+                psv[k][i] = in ? part_sum[((size_t)b * T + tt) * G + g] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int g = wave + 4 * k;
+            if (g < G) {
+                float m = fmaxf(fmaxf(pmv[k][0], pmv[k][1]), fmaxf(pmv[k][2], pmv[k][3]));
+                m = wave_max_dpp(m);
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lane + 64 * i < T) acc = acc + psv[k][i] * spec_exp(pmv[k][i] - m);
+                acc = row16_tree_sum(acc);
+                const int x = __float_as_int(acc);
+                const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+                const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+                if (lane == 0) {
+                    s_m[g] = m;
+                    s_inv[g] = 1.0f / ((r0 + r1) + (r2 + r3));
+                }
+            }
+        }
+    } else {
+        for (int g = wave; g < G; g += 4) {
+            float mx, inv;
+            softmax_finalize_wave(part_max + (size_t)b * T * G + g, part_sum + (size_t)b * T * G + g, T, G, lane, mx, inv);
+            if (lane == 0) {
+                s_m[g] = mx;
+                s_inv[g] = inv;
+            }
         }
     }
     __syncthreads();
