@@ -202,6 +202,7 @@ def run_decode(model, args, ctx, steps, warmup, walk_step, seed, world=1, pin_hi
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     h1 = int(dec.hit_accum) if dec is not None else float(hits_eager)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -211,7 +212,7 @@ def run_decode(model, args, ctx, steps, warmup, walk_step, seed, world=1, pin_hi
     if not full:
         hit_rate = (h1 - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets)
     return dict(value=aggregate_throughput([steps * bs] * world, [elapsed]), ms_per_step=elapsed / steps * 1e3,
-                hit_rate=hit_rate, mode=args.mode, slack_ring=slack_ring)
+                hit_rate=hit_rate, mode=args.mode, slack_ring=slack_ring, elapsed_local=elapsed_local, steps=steps)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -301,7 +302,7 @@ def measure_path_only(model, walk_step, steps=8):
     return dt * 1e3, hit_rate
 
 
-def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=30.0):
+def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=20.0):
     """The oracle (CPU restatement, C / OpenMP, loops spread over tiles and rows so every host core takes part) timed
     on this box's host cores: the ShadowKV path of ALL layers' state for `warm` + `timed` decode steps (fewer if a step
     takes so long that the sample would exceed ~budget_s), plus torch-CPU bf16 F.linear over one layer's dense
@@ -390,7 +391,8 @@ def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=30.0):
     dense_ms_layer = sum(reps[1:]) / 3
     head_ms = dense_ms_layer * (cfg.vocab_size * cfg.hidden_size) / sum(t.numel() for t in w)
     ms_token = path_ms_token + dense_ms_layer * L + head_ms
-    return dict(value=round(1e3 / ms_token, 4), unit="tokens/s", cores=threads, threads_used=threads, logical_cpus=os.cpu_count(),
+    return dict(value=round(1e3 / ms_token, 4), unit="tokens/s", cores=physical_cores() or threads, threads_used=threads,
+                logical_cpus=os.cpu_count(),
                 cpu_model=cpu_model_name(), kind="port",
                 sample=(f"oracle (C/OpenMP, {threads} threads) ShadowKV path over all {L} layers' state, {warm_done} warm-up + "
                         f"{n_timed} timed decode steps ({path_ms_token:.0f} ms/token = {path_ms_token / L:.1f} ms/layer) + torch-CPU bf16 "
@@ -398,6 +400,151 @@ def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=30.0):
                 path_ms_per_token=round(path_ms_token, 1), path_ms_per_layer=round(path_ms_token / L, 2),
                 dense_ms_per_layer=round(dense_ms_layer, 2), timed_steps=n_timed)
 
+
+
+DMA_CEILING_GBS = 57.0  # hipMemcpyAsync H2D of 256 MiB on this link (profiles/r01_pcie_probe.txt): what "the link" can carry
+
+
+def physical_cores():
+    """Physical cores of the box (sockets x cores; SMT siblings counted once)."""
+    try:
+        seen = set()
+        for d in os.listdir("/sys/devices/system/cpu"):
+            if d.startswith("cpu") and d[3:].isdigit():
+                base = f"/sys/devices/system/cpu/{d}/topology"
+                seen.add((open(base + "/physical_package_id").read().strip(), open(base + "/core_id").read().strip()))
+        return len(seen) or None
+    except Exception:
+        return None
+
+
+def numa_node_of_address(addr):
+    """NUMA node of the page holding `addr` in this process (move_pages query, nothing is moved); None if unavailable."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        page = ctypes.c_void_p(addr & ~4095)
+        status = ctypes.c_int(-1)
+        rc = libc.syscall(279, 0, ctypes.c_ulong(1), ctypes.byref(page), None, ctypes.byref(status), 0)   # __NR_move_pages (x86-64)
+        return int(status.value) if rc == 0 and status.value >= 0 else None
+    except Exception:
+        return None
+
+
+def process_numa_node():
+    """NUMA node of the CPU this process runs on right now."""
+    try:
+        cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
+        if cpu is None:
+            return None
+        for d in os.listdir(f"/sys/devices/system/cpu/cpu{cpu}"):
+            if d.startswith("node") and d[4:].isdigit():
+                return int(d[4:])
+    except Exception:
+        pass
+    return None
+
+
+def rank_record(rank, local_rank, model, head, t_build, numa_gpu):
+    """What a bad scaling curve would be diagnosed from: one record per rank (gathered to rank 0)."""
+    rec = dict(rank=rank, gpu_index=local_rank, tokens_per_s=round(head["steps"] * model.batch_size / head["elapsed_local"], 3),
+               ms_per_step=round(head["elapsed_local"] / head["steps"] * 1e3, 4),
+               chunk_hit_rate=None if head["hit_rate"] is None else round(head["hit_rate"], 4),
+               gpu_numa_node=numa_gpu, process_numa_node=process_numa_node(), pinned_v_numa_node=None,
+               state_build_s=round(t_build, 1), cpus_allowed=len(os.sched_getaffinity(0)))
+    try:
+        rec["gpu_pci_bus_id"] = torch.cuda.get_device_properties(local_rank).pci_bus_id
+    except Exception:
+        pass
+    c = model.kv_cache
+    v = getattr(c, "v_cache_cpu", None)
+    if v is not None and not v.is_cuda:
+        n = v.numel() * v.element_size()
+        rec["pinned_v_numa_node"] = [numa_node_of_address(v.data_ptr() + off) for off in (0, n // 2, max(0, n - 4096))]
+    return rec
+
+
+def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
+    """PCIe rate INSIDE the fetch launch (K rebuild || V fetch [|| attention]): a few eager decode steps with a pair of
+    events around every layer's fetch launch; bytes = the miss chunks of exactly those launches (per-layer hit counts)."""
+    from shadowkv_amd import llama
+    cache = model.kv_cache
+    rewind(model, ctx)
+    walk = llama.QueryWalk(model, step=walk_step, seed=seed)
+    tok = torch.randint(0, model.cfg.vocab_size, (model.batch_size, 1), device=model.device)
+    for _ in range(2):                                  # settle on the walk's hit rate
+        walk.advance()
+        tok = model.decode_step(tok, temperature=0.6, q_table=walk.qb)
+    us = 0.0
+    miss = 0
+    n = 0
+    for _ in range(steps):
+        walk.advance()
+        cache.fetch_events = []
+        tok = model.decode_step(tok, temperature=0.6, q_table=walk.qb)
+        torch.cuda.synchronize()
+        ev, cache.fetch_events = cache.fetch_events, None
+        us += sum(a.elapsed_time(b) for a, b, _ in ev) * 1e3
+        n += len(ev)
+        miss += int(cache.block_num * cache.select_sets * model.num_layers - int(cache._cnts_layers.sum()))
+    rewind(model, ctx)
+    nbytes = miss * cache.chunk_size * cache.head_dim * 2
+    gbs = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return dict(us_per_layer=round(us / max(n, 1), 2), miss_chunks_per_layer=round(miss / max(n, 1), 1),
+                bytes_per_layer=int(nbytes / max(n, 1)), pcie_gbs=round(gbs, 2),
+                frac_of_dma_ceiling=round(gbs / DMA_CEILING_GBS, 3), dma_ceiling_gbs=DMA_CEILING_GBS,
+                frac_of_spec=round(gbs / PCIE_PEAK_GBS, 3), launches=n,
+                how="torch.cuda.Event pair around every layer's fetch launch over %d eager decode steps" % steps)
+
+
+def run_call_order(model, ctx, steps, warmup, walk_step, seed):
+    """The drop-in path: DecoderLM.decode_step(fused=False) = the reference's call order (inference -> layer_compute:
+    pre_attention_compute, apply_rotary_pos_emb, update_kv_cache, get_retrieval_position_ids, get_value_cache under
+    copy_stream || get_key_cache, attention, post_attention_compute; models/base.py:315-341, models/llama.py:354-427),
+    the reference's slot order, eager launches, per-step host read of the token."""
+    from shadowkv_amd import llama
+    cache = model.kv_cache
+    rewind(model, ctx)
+    walk = llama.QueryWalk(model, step=walk_step, seed=seed)
+    model.query_hook = walk
+    tok = torch.randint(0, model.cfg.vocab_size, (model.batch_size, 1), device=model.device)
+    hits = torch.zeros((), device=model.device, dtype=torch.float64)
+    try:
+        def step():
+            nonlocal tok
+            walk.advance()
+            tok = model.decode_step(tok, temperature=0.6, fused=False)
+            hits.add_(cache._cnts_layers.sum())
+            return tok[:, -1].tolist()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        h0 = float(hits)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        model.query_hook = None
+        rewind(model, ctx)
+    return dict(value=round(steps * model.batch_size / dt, 2), ms_per_step=round(dt / steps * 1e3, 4),
+                chunk_hit_rate=round((float(hits) - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets), 4),
+                steps=steps, warmup=warmup, launch_mode="eager",
+                note="decode_step(fused=False): reference call order through layer_compute / copy_stream / the "
+                     "reference-shaped cache methods (what INTEGRATION.md's three changed imports run)")
+
+
+def free_model():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def clone_args(args, **kw):
+    d = dict(vars(args))
+    d.update(kw)
+    return argparse.Namespace(**d)
 
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
@@ -432,6 +579,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
+    ap.add_argument("--no-batched", action="store_true", help="skip the bs 8 / bs 24 lines (the reference's published regime)")
+    ap.add_argument("--no-pair", action="store_true", help="skip the e2e-style full-attention / ShadowKV pair")
+    ap.add_argument("--batched", default="8,24", help="batch sizes of the `batched` entries of the default run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -455,6 +605,13 @@ def main():
     cache = model.kv_cache
     head = run_decode(model, args, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, world=world,
                       pin_hit=args.pin_hit_rate)
+
+    # one diagnostic record per rank, gathered to rank 0 (no effect on the timed region above)
+    my_rec = rank_record(rank, local_rank, model, head, t_build, numa)
+    per_rank = [my_rec]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, my_rec)
 
     if rank == 0:
         extras = {}
@@ -491,6 +648,11 @@ def main():
                                                         chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
                                                         note="--layout reference --overlap-attention 0: the reference's slot order bit for bit")
                 model.chunk_layout, model.overlap_attention = "inplace", bool(args.overlap_attention)
+            if ref_set and bs == 1:
+                extras["value_call_order"] = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step,
+                                                            seed=99 + rank)
+            if ref_set and args.layout == "inplace" and args.query_mode == "walk":
+                extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
         if os.path.exists(pmc_path) and args.workload == "llama31_122k" and bs == 1:
@@ -511,7 +673,10 @@ def main():
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
             "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
             "launch_mode": head["mode"], "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
-            "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa,
+            "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa, "per_rank": per_rank,
+            "parity_note": "selection path bit-exact against the CPU oracle; top-k stage pinned to the reference's torch.topk "
+                           "(set-equal modulo ties); scoring vs the reference's CUTLASS softmax is pinned by bound only "
+                           "(parity unpinned: un-vendored CUTLASS), K rebuild by tolerance (MFMA accumulation order)",
         }
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -550,6 +715,71 @@ def main():
                                                  chunk_hit_rate=round(r["hit_rate"], 4), steps=32, warmup=12,
                                                  note="--resident-sets 512: least-recently-selected replacement over 512 "
                                                       "slots per head, attention over the 256 selected chunks as before")
+        default_line = (detail and args.workload == "llama31_122k" and bs == 1 and args.layers is None and args.mode == "graph"
+                        and args.layout == "inplace" and args.resident_sets is None and args.v_table == "host")
+        best_batched = None
+        if default_line and not args.no_batched:
+            # the reference's own regime (test/e2e.py:63-68, index.html:210-214: bs 24 at 122K on an A100 = 245.90 tok/s):
+            # sequences per GPU > 1, V in pinned host memory, captured step
+            out["batched"] = []
+            for b in [int(x) for x in args.batched.split(",") if x]:
+                model = cache = None
+                free_model()
+                a2 = clone_args(args, batch=b)
+                try:
+                    model, _, ctxb, _, tb = build_model(args.workload, a2, rank, dev)
+                except (MemoryError, RuntimeError) as e:          # e.g. the 197 GB pinned V table of bs 24 does not fit the box
+                    out["batched"].append(dict(batch=b, skipped=f"{type(e).__name__}: {str(e)[:200]}"))
+                    model = None
+                    continue
+                r = run_decode(model, a2, ctxb, 16, 4, args.walk_step, seed=99 + rank)
+                ent = dict(batch=b, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                           chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4, launch_mode=r["mode"],
+                           state_build_s=round(tb, 1), v_table="pinned host memory",
+                           fetch_launch=measure_fetch_launch(model, ctxb, args.walk_step, steps=2))
+                if b == 24:
+                    ent["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100",
+                                                             "source": "index.html:210-214 (config test/e2e.py:63-68)",
+                                                             "note": "other hardware: context only, never a vs_baseline"}
+                out["batched"].append(ent)
+                if best_batched is None or ent["value"] > best_batched["value"]:
+                    best_batched = ent
+        if default_line and not args.no_pair:
+            # e2e-style pair (test/e2e.py:140-168): full attention at the largest batch whose KV cache fits the GPU against
+            # ShadowKV at its own largest measured batch
+            model = cache = None
+            free_model()
+            cfg1 = WORKLOADS[args.workload]
+            free_b, _ = torch.cuda.mem_get_info()
+            from shadowkv_amd import llama as _ll
+            c1 = getattr(_ll, cfg1[0])
+            per_seq = 2 * c1.num_hidden_layers * c1.num_key_value_heads * (cfg1[1] + 1024) * 128 * 2
+            b_full = int((free_b - c1.vocab_size * c1.hidden_size * 4 - 15.2e9 - 8e9) // per_seq)
+            pair = dict(note="test/e2e.py:140-168 style: full attention at the largest batch whose KV cache fits HBM vs "
+                             "ShadowKV at its largest measured batch, same kernels for the dense layers")
+            if b_full >= 1:
+                a3 = clone_args(args, batch=b_full, attn="full")
+                model, _, ctxf, _, tb = build_model(args.workload, a3, rank, dev)
+                r = run_decode(model, a3, ctxf, 8, 2, args.walk_step, seed=99 + rank)
+                pair["full_attention"] = dict(batch=b_full, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                              steps=8, warmup=2, kv_cache_gb=round(per_seq * b_full / 1e9, 1), state_build_s=round(tb, 1))
+                model = None
+                free_model()
+                # ShadowKV with the chunked V table in HBM at bs 16 (fits 288 GB; NOT the north-star layout: V is not offloaded)
+                a4 = clone_args(args, batch=16, v_table="hbm")
+                model, _, ctxh, _, tb = build_model(args.workload, a4, rank, dev)
+                r = run_decode(model, a4, ctxh, 16, 4, args.walk_step, seed=99 + rank)
+                pair["shadowkv_v_in_hbm_bs16"] = dict(batch=16, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                      chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4,
+                                                      note="--v-table hbm: V chunks in HBM instead of pinned host memory "
+                                                           "(MI355X fits it, the A100 could not); not the north-star layout")
+                model = None
+                free_model()
+            if best_batched is not None:
+                pair["shadowkv"] = dict(batch=best_batched["batch"], value=best_batched["value"], ms_per_step=best_batched["ms_per_step"])
+                if "full_attention" in pair:
+                    pair["ratio"] = round(best_batched["value"] / pair["full_attention"]["value"], 3)
+            out["speedup_vs_full_attention"] = pair
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

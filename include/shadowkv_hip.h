@@ -351,13 +351,23 @@ SKV_EXPORT int skv_sample_advance(const float* vals, const int64_t* idx, int bat
                        const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, skv_stream_t stream);
 
 /* skv_sample_advance with the top-k inside: logits bf16 [bs][row_stride] straight from the lm_head (vocab % 8 == 0, vocab
- * <= 131,072, 16-B aligned rows), exact top-k by value (ties at the k-th value -> lowest token id), then temperature,
- * top-p, draw and counters as above - one launch for torch.topk + sample_token + the step bookkeeping. */
+ * <= 524,288, 16-B aligned rows; rows beyond 131,072 logits - GLM-4: 151,552 - are searched in equal parts and merged),
+ * exact k-th largest value; every logit above it and EVERY logit tied with it stays (the reference's filter removes logits
+ * < the k-th value, /root/reference/models/tensor_op.py:253-255), at most 64 candidates (beyond: lowest token ids of the
+ * tied ones); then logit / temperature, top-p, draw and counters as above - one launch for top_k_top_p_filter +
+ * multinomial + the step bookkeeping. */
 SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
                             float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
                             int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
                             long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
                             int64_t* hit_accum, skv_stream_t stream);
+
+/* Page-locked, device-mapped host memory of EXACTLY nbytes for the chunked V table (hipHostMalloc through the HIP runtime
+ * this library is linked against - the one the caller's streams and tensors come from).  The reference pins V with
+ * torch.zeros(..., pin_memory=True) (/root/reference/models/kv_cache.py:554-563); torch's pinned allocator rounds 8.19 GB
+ * up to 16 GiB, so the cache allocates the table here.  Not launchers: they allocate / free and must not be captured. */
+SKV_EXPORT int skv_host_alloc(void** out, size_t nbytes);
+SKV_EXPORT int skv_host_free(void* p);
 
 /* ---- part 4: prefill-side state builder ---------------------------------------- */
 

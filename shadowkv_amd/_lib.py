@@ -57,6 +57,8 @@ _SIGS = {
     "skv_qkv_gemv_rope_update": (c_int, [c_p] * 4 + [c_f] + [c_p] * 9 + [c_int] * 4 + [c_ll, c_int, c_ll] + [c_int] * 2 + [c_p]),
     "skv_gemv_bf16": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),
     "skv_chunk_stats": (c_int, [c_p, c_ll] + [c_int] * 4 + [c_p] * 3),
+    "skv_host_alloc": (c_int, [ctypes.POINTER(c_p), c_sz]),
+    "skv_host_free": (c_int, [c_p]),
     "skv_linear_rows_bf16": (c_int, [c_p] * 4 + [c_int] * 4 + [c_p]),
     "skv_sparse_attention": (c_int, [c_p] * 6 + [c_int, c_int, c_ll] + [c_int] * 5 + [c_f, c_p]),
     "skv_sparse_attention_slots": (c_int, [c_p] * 6 + [c_int, c_int, c_ll] + [c_int] * 5 + [c_f, c_p] + [c_int] * 3 + [c_p]),

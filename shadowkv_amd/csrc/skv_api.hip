@@ -68,6 +68,23 @@ static int finish(int rc) {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+extern "C" int skv_host_alloc(void** out, size_t nbytes) {
+    if (!out || nbytes == 0) return SKV_ERR_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, nbytes, hipHostMallocDefault);
+    if (e != hipSuccess || !*out) {
+        strncpy(g_err, hipGetErrorString(e), sizeof(g_err) - 1);
+        (void)hipGetLastError();
+        return SKV_ERR_LAUNCH;
+    }
+    return SKV_OK;
+}
+
+extern "C" int skv_host_free(void* p) {
+    if (!p) return SKV_OK;
+    return hipHostFree(p) == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+}
+
 struct SelectWs {
     void* D;
     float* pmax;

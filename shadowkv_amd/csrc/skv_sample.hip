@@ -74,7 +74,9 @@ __global__ __launch_bounds__(64) void skv_sample_advance_kernel(
 // radix-sort / partition launches per token at bs = 1; its multi-block path faulted under hipGraph replay for bs > 1) +
 // the f32 conversion and division of the whole logit row.  The selection is the front end of the chunk-selection kernel
 // (skv_select_front.h): the row lives in registers, one 4,096-bin histogram pass finds the k-th largest value, an
-// ordered compaction collects the k winners (ties at the k-th value -> lowest token id; torch.topk leaves that open).
+// ordered compaction collects the winners: every logit above the k-th largest value and ALL logits equal to it (the
+// reference's filter removes only logits < the k-th value, models/tensor_op.py:253-255), 64 winners at most - beyond
+// that the lowest token ids among the tied ones.
 // Signed bf16 logits are mapped to order-preserving unsigned 16-bit keys first.  One 1,024-thread workgroup per sequence.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bf16x2_to_keys(uint32_t w) {       // x >= 0: x | 0x8000;  x < 0: ~x
@@ -87,28 +89,24 @@ __device__ __forceinline__ float key_to_float(int key) {
 }
 
 #define SMP_CAND (2 * T2_THREADS)    // candidates the exact search takes (two per thread)
+#define SMP_KEEP 64                  // winners a row (or a part of it) can hand on: k plus the logits tied with the k-th
+#define SMP_PARTS 4                  // a row is searched in parts of <= 131,072 logits (16 vectors per thread)
+
+// Exact top-k of ONE part of a logit row (Vp <= 131,072 logits starting at `row`), all 1,024 threads: the part lives in
+// registers, the k-th largest of the 1,024 per-thread maxima bounds the candidates, the exact search (4,096-bin histogram
+// counted down from the maximum, skv_select_front.h) runs on those few dozen.  Leaves in s_cur[0 .. n) the LOCAL ids,
+// ascending, of every logit > thr and of the logits == thr (thr = the k-th largest value) in ascending id order - ALL of
+// them, as the reference's filter keeps every logit that is not < the k-th value (models/tensor_op.py:253-255), up to
+// SMP_KEEP winners in all; returns n (uniform).  Ends with a barrier.
 template <int SEGV>
-__global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
-    const bf16_t* __restrict__ logits, long long row_stride, int V, int k, float inv_temp, float top_p,
-    unsigned long long seed, int64_t* __restrict__ token, int64_t* __restrict__ pos, int64_t* __restrict__ gen,
-    int64_t* __restrict__ row_idx, int32_t* __restrict__ kv_len, int64_t* __restrict__ step_idx, long long base,
-    long long slack, long long table_len, const int32_t* __restrict__ hit_cnts, int n_hit_cnts,
-    int64_t* __restrict__ hit_accum) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
-    int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
-    int* s_out = s_w + 80;                            // [16]
-    int* s_cur = s_out + 16;                          // [64] token id per selected position (ascending id)
-    int* s_cidx = s_cur + 64;                         // [SMP_CAND] token ids of the prefilter's candidates, ascending
-    float* s_sv = reinterpret_cast<float*>(s_cidx + SMP_CAND);   // [64] sorted: logit / temperature, descending
-    int* s_si = reinterpret_cast<int*>(s_sv + 64);    // [64] sorted: token id
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, const int Vp, const int k, const int tid,
+                                                int* s_hist, int* s_w, int* s_out, int* s_cidx, int* s_cur) {
     constexpr int NW = 4 * SEGV, NG = (NW + 15) / 16;
     uint32_t w[NW];
     const int j0 = tid * SEGV * 8;
     {
-        const u32x4* gvec = reinterpret_cast<const u32x4*>(logits + (size_t)b * row_stride);
-        const int nvec = V / 8;
+        const u32x4* gvec = reinterpret_cast<const u32x4*>(row);
+        const int nvec = Vp / 8;
 #pragma unroll
         for (int q = 0; q < SEGV; ++q) {
             const int vi = tid * SEGV + q;
@@ -126,6 +124,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     // distinct logits are >= L), so only logits >= L can be winners: a few dozen of 128 K.  They are compacted (token
     // order) and the exact search runs on them: one histogram atomic per thread instead of 8 * SEGV * ... per thread.
     bool done = false;
+    int n_out = 0;
     {
         uint32_t m2 = w[0];
 #pragma unroll
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
         if (C <= SMP_CAND) {                                              // (always, unless thousands of logits tie)
             const int c0 = 2 * tid, c1 = 2 * tid + 1;
             const int id0 = c0 < C ? s_cidx[c0] : -1, id1 = c1 < C ? s_cidx[c1] : -1;
-            const bf16_t* row = logits + (size_t)b * row_stride;
             const uint32_t k0 = bf16x2_to_keys((uint32_t)row[max(id0, 0)]) & 0xffffu, k1 = bf16x2_to_keys((uint32_t)row[max(id1, 0)]) & 0xffffu;
             const uint32_t w2[1] = {(id0 >= 0 ? k0 : 0u) | ((id1 >= 0 ? k1 : 0u) << 16)};
             int thr, need_eq;
@@ -175,87 +173,146 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
             const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
             const bool v0 = id0 >= 0, v1 = id1 >= 0;
             const int g0 = v0 && lo > thr, g1 = v1 && hi > thr, e0 = v0 && lo == thr, e1 = v1 && hi == thr;
-            const int packed = (g0 + g1) | (min(e0 + e1, need_eq) << 10);
-            const int pexcl = block_scan_incl1(packed, s_w + 48, tid) - packed;
+            const int packed = (g0 + g1) | ((e0 + e1) << 10);             // (<= 64 greater, <= 2,048 equal in all)
+            const int pincl = block_scan_incl1(packed, s_w + 48, tid);
+            if (tid == T2_THREADS - 1) s_out[9] = pincl >> 10;            // logits equal to the k-th value
+            __syncthreads();
+            const int n_gt = k - need_eq, keep_eq = min(s_out[9], SMP_KEEP - n_gt);
+            const int pexcl = pincl - packed;
             int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
-            if (g0) s_cur[gt_run++ + min(eq_run, need_eq)] = id0;
-            else if (e0) { if (eq_run < need_eq) s_cur[gt_run + eq_run] = id0; ++eq_run; }
-            if (g1) s_cur[gt_run + min(eq_run, need_eq)] = id1;
-            else if (e1 && eq_run < need_eq) s_cur[gt_run + eq_run] = id1;
+            if (g0) s_cur[gt_run++ + min(eq_run, keep_eq)] = id0;
+            else if (e0) { if (eq_run < keep_eq) s_cur[gt_run + eq_run] = id0; ++eq_run; }
+            if (g1) s_cur[gt_run + min(eq_run, keep_eq)] = id1;
+            else if (e1 && eq_run < keep_eq) s_cur[gt_run + eq_run] = id1;
+            n_out = n_gt + keep_eq;
             done = true;
         }
     }
     if (!done) {
-    int thr, need_eq;
-    t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - V, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
-    // flags (keys use all 16 bits here: plain compares), ordered compaction as in skv_topk2_kernel
-    uint32_t mge[NG], mgt[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        mge[g] = 0u;
-        mgt[g] = 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int lo = (int)(w[i] & 0xffffu), hi = (int)(w[i] >> 16);
-        const uint32_t fe = (uint32_t)(lo >= thr) | ((uint32_t)(hi >= thr) << 1), fg = (uint32_t)(lo > thr) | ((uint32_t)(hi > thr) << 1);
-        mge[i / 16] |= fe << (2 * (i % 16));
-        mgt[i / 16] |= fg << (2 * (i % 16));
-    }
-    int cg = 0, ce = 0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        cg += __builtin_popcount(mgt[g]);
-        ce += __builtin_popcount(mge[g]);
-    }
-    ce = min(ce - cg, need_eq);
-    const int packed = cg | (ce << 10);
-    const int pexcl = block_scan_incl1(packed, s_w + 48, tid) - packed;
-    {
-        int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+        int thr, need_eq;
+        t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - Vp, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+        // flags (keys use all 16 bits here: plain compares), ordered compaction as in skv_topk2_kernel
+        uint32_t mge[NG], mgt[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            uint32_t m = mge[g];
-            while (m) {
-                const int e = __builtin_ctz(m);
-                m &= m - 1;
-                int p = -1;
-                if ((mgt[g] >> e) & 1u) {
-                    p = gt_run + min(eq_run, need_eq);
-                    ++gt_run;
-                } else {
-                    if (eq_run < need_eq) p = gt_run + eq_run;
-                    ++eq_run;
-                }
-                if (p >= 0) s_cur[p] = j0 + g * 32 + e;
+            mge[g] = 0u;
+            mgt[g] = 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int lo = (int)(w[i] & 0xffffu), hi = (int)(w[i] >> 16);
+            const uint32_t fe = (uint32_t)(lo >= thr) | ((uint32_t)(hi >= thr) << 1), fg = (uint32_t)(lo > thr) | ((uint32_t)(hi > thr) << 1);
+            mge[i / 16] |= fe << (2 * (i % 16));
+            mgt[i / 16] |= fg << (2 * (i % 16));
+        }
+        if (thr == 0) {   // (padding has key 0 and the highest ids; the k-th value can only be 0 when every logit of the part is)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int j = j0 + 2 * i;
+                const uint32_t drop = (uint32_t)(j >= Vp) | ((uint32_t)(j + 1 >= Vp) << 1);
+                mge[i / 16] &= ~(drop << (2 * (i % 16)));
             }
         }
-    }
+        int cg = 0, ce = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            cg += __builtin_popcount(mgt[g]);
+            ce += __builtin_popcount(mge[g]);
+        }
+        ce -= cg;
+        const int packed = cg | (ce << 10);                               // (< 64 greater, <= 131,072 equal in all)
+        const int pincl = block_scan_incl1(packed, s_w + 48, tid);
+        if (tid == T2_THREADS - 1) s_out[9] = pincl >> 10;
+        __syncthreads();
+        const int n_gt = k - need_eq, keep_eq = min(s_out[9], SMP_KEEP - n_gt);
+        const int pexcl = pincl - packed;
+        {
+            int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                uint32_t m = mge[g];
+                while (m) {
+                    const int e = __builtin_ctz(m);
+                    m &= m - 1;
+                    int p = -1;
+                    if ((mgt[g] >> e) & 1u) {
+                        p = gt_run + min(eq_run, keep_eq);
+                        ++gt_run;
+                    } else {
+                        if (eq_run < keep_eq) p = gt_run + eq_run;
+                        ++eq_run;
+                    }
+                    if (p >= 0) s_cur[p] = j0 + g * 32 + e;
+                }
+            }
+        }
+        n_out = n_gt + keep_eq;
     }
     __syncthreads();
-    // ---- sort the k winners by (value descending, token id ascending): rank by counting, one lane per winner
-    if (tid < 64) {
-        const bool in = lane < k;
-        const int id = in ? s_cur[lane] : 0x7fffffff;
-        // the winner's logit is read back (L2-hot) rather than dug out of the register row by a run-time index
-        const int key = in ? (int)(bf16x2_to_keys((uint32_t)logits[(size_t)b * row_stride + id]) & 0xffffu) : -1;
-        int rank = 0;
-        for (int m = 0; m < k; ++m) {
-            const int ko = __builtin_amdgcn_readlane(key, m), io = __builtin_amdgcn_readlane(id, m);
+    return n_out;
+}
+
+template <int SEGV>
+__global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
+    const bf16_t* __restrict__ logits, long long row_stride, int V, int parts, int part_len, int k, float temperature,
+    float top_p, unsigned long long seed, int64_t* __restrict__ token, int64_t* __restrict__ pos, int64_t* __restrict__ gen,
+    int64_t* __restrict__ row_idx, int32_t* __restrict__ kv_len, int64_t* __restrict__ step_idx, long long base,
+    long long slack, long long table_len, const int32_t* __restrict__ hit_cnts, int n_hit_cnts,
+    int64_t* __restrict__ hit_accum) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
+    int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
+    int* s_out = s_w + 80;                            // [16]
+    int* s_cur = s_out + 16;                          // [64] local token id per winner of the current part (ascending id)
+    int* s_cidx = s_cur + 64;                         // [SMP_CAND] token ids of the prefilter's candidates, ascending
+    float* s_sv = reinterpret_cast<float*>(s_cidx + SMP_CAND);   // [64] sorted: logit / temperature, descending
+    int* s_si = reinterpret_cast<int*>(s_sv + 64);    // [64] sorted: token id
+    int* s_ck = s_si + 64;                            // [SMP_PARTS * 64] key of every part's winners (-1: none)
+    int* s_ci = s_ck + SMP_PARTS * SMP_KEEP;          // [SMP_PARTS * 64] their token ids
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bf16_t* const row = logits + (size_t)b * row_stride;
+    // ---- the winners of every part (a row of <= 131,072 logits is one part)
+    for (int p = 0; p < parts; ++p) {
+        const int v0 = p * part_len, vp = min(part_len, V - v0);
+        const int n = sample_part_topk<SEGV>(row + v0, vp, min(k, vp), tid, s_hist, s_w, s_out, s_cidx, s_cur);
+        if (tid < SMP_KEEP) {
+            const int id = tid < n ? v0 + s_cur[tid] : 0x7fffffff;
+            // the winner's logit is read back (L2-hot) rather than dug out of the register row by a run-time index
+            s_ck[p * SMP_KEEP + tid] = tid < n ? (int)(bf16x2_to_keys((uint32_t)row[id]) & 0xffffu) : -1;
+            s_ci[p * SMP_KEEP + tid] = id;
+        }
+        if (tid == 0 && p == 0) s_out[12] = 0;
+        __syncthreads();
+    }
+    // ---- merge: rank every winner by (value descending, token id ascending); the k-th of them is the k-th largest logit
+    // of the row; everything not below it stays (up to SMP_KEEP), already in sorted order by its rank
+    const int nc = parts * SMP_KEEP;
+    int key = -1, id = 0x7fffffff, rank = 0x7fffffff;
+    if (tid < nc) {
+        key = s_ck[tid];
+        id = s_ci[tid];
+        rank = 0;
+        for (int m = 0; m < nc; ++m) {
+            const int ko = s_ck[m], io = s_ci[m];
             rank += (ko > key) || (ko == key && io < id);
         }
-        if (in) {
-            s_sv[rank] = key_to_float(key) * inv_temp;
-            s_si[rank] = id;
-        }
+        if (key >= 0 && rank == k - 1) s_out[11] = key;
+    }
+    __syncthreads();
+    if (tid < nc && key >= s_out[11]) atomicMax(&s_out[12], rank + 1);     // (key >= thr >= 0: a winner)
+    __syncthreads();
+    const int kk = min(s_out[12], SMP_KEEP);
+    if (tid < nc && rank < kk) {
+        s_sv[rank] = key_to_float(key) / temperature;
+        s_si[rank] = id;
     }
     __syncthreads();
     if (tid >= 64) return;
     // ---- top-p, draw, counters: as skv_sample_advance_kernel
     const long long p0 = pos[b];
-    const float v = lane < k ? s_sv[lane] : -INFINITY;
+    const float v = lane < kk ? s_sv[lane] : -INFINITY;
     const float mx = wave_max_dpp(v);
-    const float e = lane < k ? __expf(v - mx) : 0.f;
+    const float e = lane < kk ? __expf(v - mx) : 0.f;
     const float tot = wave_tree_sum(e);
     const float p = e / tot;
     float c = p;
@@ -264,7 +321,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
         const float n = __shfl_up(c, o, 64);
         if (lane >= o) c += n;
     }
-    const bool keep = lane < k && (top_p <= 0.f || lane == 0 || (c - p) <= top_p);
+    const bool keep = lane < kk && (top_p <= 0.f || lane == 0 || (c - p) <= top_p);
     const float pk = keep ? e : 0.f;
     uint32_t h = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9u * (uint32_t)p0));
     h = mix32(h ^ (0x85ebca6bu * (uint32_t)(b + 1)) ^ (0xc2b2ae35u * (uint32_t)(lane + 1)) ^ (uint32_t)(p0 >> 32));
@@ -293,21 +350,30 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     }
 }
 
+// MaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one flag per (kernel, device)
+static bool attr_needed(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 template <int SEGV>
-static int launch_sample_topk(const void* logits, long long row_stride, int V, int bs, int k, float temperature, float top_p,
-                              unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
-                              int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
-                              const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, hipStream_t st) {
-    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3 + SMP_CAND) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+static int launch_sample_topk(const void* logits, long long row_stride, int V, int parts, int part_len, int bs, int k,
+                              float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
+                              int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                              long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                              int64_t* hit_accum, hipStream_t st) {
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3 + SMP_CAND + 2 * SMP_PARTS * SMP_KEEP) * sizeof(int);
+    static bool attr_set[64] = {};
+    if (attr_needed(attr_set)) {
         if (hipFuncSetAttribute((const void*)skv_sample_topk_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return SKV_ERR_LAUNCH;
-        attr_set = true;
     }
     hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
-                       V, k, 1.0f / temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
+                       V, parts, part_len, k, temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
                        table_len, hit_cnts, n_hit_cnts, hit_accum);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
@@ -319,11 +385,17 @@ extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride,
                                        int64_t* hit_accum, skv_stream_t stream) {
     if (!logits || !token || !pos || !gen || !row_idx || !kv_len || batch_size < 1 || !(temperature > 0.f)) return SKV_ERR_ARG;
     if (k < 1 || k > 64 || vocab < k || slack < 1 || (step_idx && table_len < 1)) return SKV_ERR_UNSUPPORTED;
-    if ((vocab % 8) || (row_stride % 8) || (((size_t)logits) & 15) || vocab > T2_THREADS * 16 * 8) return SKV_ERR_UNSUPPORTED;
+    constexpr int PART_MAX = T2_THREADS * 16 * 8;          // logits one pass holds in registers
+    if ((vocab % 8) || (row_stride % 8) || (((size_t)logits) & 15) || vocab > SMP_PARTS * PART_MAX) return SKV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int per_thread = (vocab / 8 + T2_THREADS - 1) / T2_THREADS;
-#define SKV_ST(SV) launch_sample_topk<SV>(logits, row_stride, vocab, batch_size, k, temperature, top_p, seed, token, pos, gen, \
-                                          row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum, st)
+    // rows beyond 131,072 logits (GLM-4: 151,552) are searched in equal parts, each a multiple of 8 logits
+    const int parts = (vocab + PART_MAX - 1) / PART_MAX;
+    const int part_len = (((vocab + parts - 1) / parts) + 7) & ~7;
+    if (vocab - (parts - 1) * part_len < k) return SKV_ERR_UNSUPPORTED;   // (never for real vocabularies)
+    const int per_thread = (part_len / 8 + T2_THREADS - 1) / T2_THREADS;
+#define SKV_ST(SV) launch_sample_topk<SV>(logits, row_stride, vocab, parts, part_len, batch_size, k, temperature, top_p, seed, \
+                                          token, pos, gen, row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts,         \
+                                          n_hit_cnts, hit_accum, st)
     if (per_thread <= 1) return SKV_ST(1);
     if (per_thread <= 2) return SKV_ST(2);
     if (per_thread <= 4) return SKV_ST(4);

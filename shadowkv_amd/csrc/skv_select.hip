@@ -32,13 +32,51 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef SKV_SCORE_WAVES
 #define SKV_SCORE_WAVES 16                      // waves per 256-landmark tile (16 rows each; 4/8/16 measured: 9.3 / 8.8 / 8.5 us)
 #endif
+#ifndef SKV_SCORE_PD
+#define SKV_SCORE_PD 2                          // row-group loads a wave keeps in flight (see the kernel comment)
+#endif
+// One row group (4 landmark rows of one wave-instruction) against GH query heads held in registers: per-lane fma chain over
+// the lane's 8 elements (two heads per v_pk_fma_f32), transposing 16-lane butterfly, one bf16 logit per lane into the tile.
+template <int GH>
+__device__ __forceinline__ void score_row_group(const f32x2 (&qf)[(GH + 1) / 2][8], const u32x4 xv, bf16_t* sD_g0 /* &sD[g0][0] */,
+                                                int col, int lane, float alpha) {
+    constexpr int GP = (GH + 1) / 2;
+    float xf[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xf[2 * j] = bf_lo(xv[j]);
+        xf[2 * j + 1] = bf_hi(xv[j]);
+    }
+    f32x2 acc2[GP];
+#pragma unroll
+    for (int gp = 0; gp < GP; ++gp) {
+        acc2[gp] = (f32x2){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc2[gp] = __builtin_elementwise_fma(qf[gp][j], (f32x2){xf[j], xf[j]}, acc2[gp]);
+    }
+    float part[GH];
+#pragma unroll
+    for (int g = 0; g < GH; ++g) part[g] = (g & 1) ? acc2[g / 2].y : acc2[g / 2].x;
+    const float tot = row16_tree_sum_transposed<GH>(part, lane);
+    if (row16_publisher<GH>(lane)) sD_g0[row16_owner<GH>(lane) * SKV_TILE + col] = f2bf(alpha * tot);
+}
+
 // ABL (ablation, diagnostic builds only - tools/score_probe.hip): 0 = the kernel; 1 = loads only (no dot
 // products); 2 = no per-tile statistics tail.  The library instantiates ABL = 0 only.
-// WAVES per tile: 16 (measured best for G <= 4: 4 / 8 / 16 waves 9.3 / 8.8 / 8.5 us); G = 8 (GLM) takes 8: its q fragment
-// alone is 64 VGPRs, 100 in all - with 16 waves per workgroup only ONE workgroup fits a CU and the 400 workgroups of the
-// 200K configuration ran in two rounds (12.0 us for 26 MB); 8 waves of ~120 VGPRs fit twice, all 400 are resident at once.
-template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES)>
-__global__ __launch_bounds__(64 * WAVES) void skv_score_tile_kernel(
+//
+// Round 3: (1) the loads of a wave are PIPELINED (PD row groups in flight, the next one is requested when the oldest has
+// arrived) instead of all 64 KB of a tile being requested in the first microsecond.  The memory system serves requests
+// roughly in arrival order, so with everything requested up front the workgroups dispatched last received their whole tile
+// last and then still had all of its arithmetic to do, exposed, while the early workgroups' CUs idled: the kernel took
+// "loads only" + the arithmetic of one or two tiles per CU (6.4 + 1.6 us at G = 4, tools/score_probe.hip).  With a bounded
+// depth per wave a CU that holds two tiles also draws twice the bandwidth of a CU that holds one, so the 400-488 tiles of
+// a launch finish together whatever 256 does to their count.  (2) More than 4 query heads per KV head (GLM: 8) run as
+// PASSES of 4 over the SAME landmark registers: the q fragment of 8 heads alone was 64 VGPRs (100-120 in all, 8 waves per
+// tile, two tiles per CU at best); a pass needs 32, the kernel stays at 64 VGPRs and 16 waves per tile like G = 4.  The later
+// passes' query heads wait in a wave-private LDS copy (no barrier).  Results are bit-identical: every head's total is the
+// same fma chain and the same 16-lane tree whichever other heads travel through the butterfly with it.
+template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES), int PD = (G == 8 ? 3 : SKV_SCORE_PD)>
+__global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void skv_score_tile_kernel(
     const bf16_t* __restrict__ q,    // [B][G][128]
     const bf16_t* __restrict__ lm,   // [B][N][128]
     bf16_t* __restrict__ D,          // [B][G][N]
@@ -46,63 +84,90 @@ __global__ __launch_bounds__(64 * WAVES) void skv_score_tile_kernel(
     float* __restrict__ part_sum,    // [B][T][G]
     int N, int T, float alpha) {
     constexpr int ITERS = 64 / WAVES;               // 4-row wave-instructions per wave
+    constexpr int GH = G > 8 ? 4 : G;               // query heads per pass
+    constexpr int PASSES = G / GH;
+    constexpr int GP = (GH + 1) / 2;
+    constexpr int DEPTH = PD < ITERS ? PD : ITERS;
+    static_assert(G % GH == 0, "G must be 1, 2, 4, 8 or a multiple of 4");
     const int b = blockIdx.y, t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, rsel = lane >> 4;
     __shared__ __attribute__((aligned(16))) bf16_t sD[G][SKV_TILE];
+    // query heads of passes 1.. : one private copy per wave (written and read by the same wave: no barrier)
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[PASSES > 1 ? WAVES : 1][PASSES > 1 ? (G - GH) * 128 : 8];
 
-    // q fragment: G x 8 floats, packed in pairs of query heads for v_pk_fma_f32
-    constexpr int GP = (G + 1) / 2;
+    // q fragment of the first pass: GH x 8 floats, packed in pairs of query heads for v_pk_fma_f32
     f32x2 qf[GP][8];
-#pragma unroll
-    for (int gp = 0; gp < GP; ++gp) {
-        u32x4 w0 = *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp) * 128 + 8 * sub);
-        u32x4 w1 = (2 * gp + 1 < G) ? *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp + 1) * 128 + 8 * sub) : w0;
+    auto unpack_q = [&](int gp, const u32x4 w0, const u32x4 w1) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             qf[gp][2 * j] = (f32x2){bf_lo(w0[j]), bf_lo(w1[j])};
             qf[gp][2 * j + 1] = (f32x2){bf_hi(w0[j]), bf_hi(w1[j])};
         }
+    };
+#pragma unroll
+    for (int gp = 0; gp < GP; ++gp) {
+        u32x4 w0 = *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp) * 128 + 8 * sub);
+        u32x4 w1 = (2 * gp + 1 < GH) ? *reinterpret_cast<const u32x4*>(q + ((size_t)b * G + 2 * gp + 1) * 128 + 8 * sub) : w0;
+        unpack_q(gp, w0, w1);
+    }
+    if constexpr (PASSES > 1) {
+        constexpr int QV = (G - GH) * 16;           // 16-B units of the later passes' heads
+#pragma unroll
+        for (int k = 0; k < (QV + 63) / 64; ++k) {
+            const int u = lane + 64 * k;
+            if (u < QV) reinterpret_cast<u32x4*>(&sQ[wave][0])[u] = reinterpret_cast<const u32x4*>(q + ((size_t)b * G + GH) * 128)[u];
+        }
     }
 
     const int row0 = t * SKV_TILE + wave * (4 * ITERS) + rsel;
     u32x4 x[ITERS];
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
+    auto request = [&](int i) __attribute__((always_inline)) {
         int row = row0 + i * 4;
         row = row < N ? row : N - 1;  // clamp: out-of-range rows are computed and discarded
         x[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lm + ((size_t)b * N + row) * 128 + 8 * sub));
-    }
-    const int my_g = row16_owner<G>(lane);
-    const bool publish = row16_publisher<G>(lane);
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) request(i);
     if (ABL == 1) {   // memory stream only: fold the loaded words so the loads stay, skip all arithmetic
         uint32_t f = 0;
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+        for (int i = 0; i < ITERS; ++i) {
+            if (i + DEPTH < ITERS) request(i + DEPTH);
+            f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (f == 0x12345u) D[0] = (bf16_t)f;
         return;
     }
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-        float xf[8];
+        // program order: request row group i + DEPTH, then consume row group i (the compiler's counted vmcnt wait leaves the
+        // DEPTH younger requests in flight); the scheduling barriers keep hipcc from hoisting every request to the top again
+        if (i + DEPTH < ITERS) request(i + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        score_row_group<GH>(qf, x[i], &sD[0][0], wave * (4 * ITERS) + i * 4 + rsel, lane, alpha);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PASSES > 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xf[2 * j] = bf_lo(x[i][j]);
-            xf[2 * j + 1] = bf_hi(x[i][j]);
+        for (int p = 1; p < PASSES; ++p) {
+            // the next pass's q fragment must not be built while this one is live, and the stash must really be READ here
+            // (forwarding the stored registers would keep all G heads live: that is what the stash is there to avoid)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) {
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(&sQ[wave][((p - 1) * GH + 2 * gp) * 128 + 8 * sub]);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(&sQ[wave][((p - 1) * GH + 2 * gp + 1) * 128 + 8 * sub]);
+                unpack_q(gp, w0, w1);
+            }
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                score_row_group<GH>(qf, x[i], &sD[p * GH][0], wave * (4 * ITERS) + i * 4 + rsel, lane, alpha);
+                __builtin_amdgcn_sched_barrier(0);  // one row group at a time (interleaved they need > 64 VGPRs)
+            }
         }
-        // per-lane partials: sequential fma chain over the lane's 8 elements, two heads per instruction
-        f32x2 acc2[GP];
-#pragma unroll
-        for (int gp = 0; gp < GP; ++gp) {
-            acc2[gp] = (f32x2){0.0f, 0.0f};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc2[gp] = __builtin_elementwise_fma(qf[gp][j], (f32x2){xf[j], xf[j]}, acc2[gp]);
-        }
-        float part[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) part[g] = (g & 1) ? acc2[g / 2].y : acc2[g / 2].x;
-        const float tot = row16_tree_sum_transposed<G>(part, lane);
-        if (publish) sD[my_g][wave * (4 * ITERS) + i * 4 + rsel] = f2bf(alpha * tot);
     }
     __syncthreads();
     if (ABL == 2) {

@@ -38,6 +38,7 @@ Beyond the reference's surface (opt-in, used by DecoderLM.forward_fused / bench.
 import ctypes
 import gc
 import math
+import weakref
 
 import torch
 
@@ -45,32 +46,22 @@ from . import tensor_op
 from ._lib import lib, check, ptr, current_stream_handle
 
 
-class _PinnedHostBuffer:
-    """Exact-size page-locked, device-mapped host allocation (hipHostMalloc) for the chunked V table.  torch's caching
-    pinned allocator rounds every request up to a power of two (8.19 GB -> 16 GiB per 122K-token sequence; the
-    reference's batch of 24 sequences, 197 GB, would ask for 256 GiB); the V table is allocated once and lives as long
-    as the cache, so it bypasses that allocator.  `tensor()` is a zero-copy CPU view; torch recognises the memory as
-    pinned (hipPointerGetAttributes), so GPU -> host copies into it are asynchronous DMA."""
-    _hip = None
-
-    def __init__(self, nbytes):
-        if _PinnedHostBuffer._hip is None:
-            _PinnedHostBuffer._hip = ctypes.CDLL("libamdhip64.so")
-        p = ctypes.c_void_p()
-        rc = self._hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes), ctypes.c_uint(0))
-        if rc != 0 or not p.value:
-            raise MemoryError(f"hipHostMalloc({nbytes} bytes) failed with error {rc}")
-        self.ptr, self.nbytes = p.value, nbytes
-
-    def tensor(self, shape, dtype):
-        t = torch.frombuffer((ctypes.c_char * self.nbytes).from_address(self.ptr), dtype=dtype).view(shape)
-        t._skv_owner = self                      # the view keeps the allocation alive
-        return t
-
-    def __del__(self):
-        if getattr(self, "ptr", None):
-            self._hip.hipHostFree(ctypes.c_void_p(self.ptr))
-            self.ptr = None
+def pinned_host_tensor(shape, dtype):
+    """Exact-size page-locked, device-mapped host tensor (skv_host_alloc = hipHostMalloc in the HIP runtime torch itself
+    uses: libshadowkv_hip.so is loaded after torch and resolves to the runtime already in the process) for the chunked V
+    table.  torch's caching pinned allocator rounds every request up to a power of two (8.19 GB -> 16 GiB per 122K-token
+    sequence; the reference's batch of 24 sequences, 197 GB, would ask for 256 GiB); the V table is allocated once and lives
+    as long as the cache, so it bypasses that allocator.  The memory is owned by the buffer object every view of the tensor
+    keeps alive: it is freed when the LAST view (slices such as v_cache_cpu[l] included) is gone, not when the cache is.
+    torch recognises the memory as pinned (is_pinned()), so GPU -> host copies into it are asynchronous DMA."""
+    nbytes = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+    p = ctypes.c_void_p()
+    rc = lib().skv_host_alloc(ctypes.byref(p), nbytes)
+    if rc != 0 or not p.value:
+        raise MemoryError(f"skv_host_alloc({nbytes} bytes of pinned host memory) failed: {lib().skv_last_error().decode()}")
+    buf = (ctypes.c_char * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib().skv_host_free, p.value)
+    return torch.frombuffer(buf, dtype=dtype).view(shape)
 
 
 class KV_Cache:
@@ -190,9 +181,7 @@ class ShadowKVCache_CPU:
         # same kernels then gather the misses at HBM speed; 8 GB per 122K-token sequence of the 288 GB)
         self.v_offload = bool(v_offload) or not on_gpu
         if self.v_offload and on_gpu:
-            shape = (L, bs, kv, max_length // C, D * C)
-            self._v_host = _PinnedHostBuffer(math.prod(shape) * 2)
-            self.v_cache_cpu = self._v_host.tensor(shape, dtype).zero_()
+            self.v_cache_cpu = pinned_host_tensor((L, bs, kv, max_length // C, D * C), dtype).zero_()
         elif self.v_offload:
             self.v_cache_cpu = torch.zeros(L, bs, kv, max_length // C, D * C, device="cpu", dtype=dtype)
         else:
@@ -231,6 +220,9 @@ class ShadowKVCache_CPU:
         self.output = torch.zeros(bs, kv, self.sparse_budget, D, device=self.device, dtype=dtype)
         self._staged_layer = -1
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
+        # measurement hook (bench.py): a list -> every fetch launch of the in-place path is bracketed by two events on the
+        # current stream and (start, end, layer) is appended; None (default): nothing is recorded
+        self.fetch_events = None
         self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -494,12 +486,23 @@ class ShadowKVCache_CPU:
         vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
+        ev0 = self._fetch_event()
         check(L.skv_fetch_kv_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
                                      ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), U.shape[0],
                                      self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
                                      self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
                                      kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
               "fetch_kv_inplace")
+        self._fetch_event(ev0, layer_idx)
+
+    def _fetch_event(self, start=None, layer_idx=None):
+        if self.fetch_events is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if start is not None:
+            self.fetch_events.append((start, e, layer_idx))
+        return e
 
     def attend_slot_args(self):
         """Keyword arguments for tensor_op.sparse_attention_decode after select_fetch_inplace: with a resident set larger
@@ -561,6 +564,7 @@ class ShadowKVCache_CPU:
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
         scale = 1.0 / math.sqrt(D)
+        ev0 = self._fetch_event()
         check(L.skv_fetch_kv_attn_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
                                           ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), ptr(q), ptr(ws),
                                           ptr(kv_len_dev), int(kv_len), buf_rows, U.shape[0], self.num_key_value_heads, Hq,
@@ -569,6 +573,7 @@ class ShadowKVCache_CPU:
                                           self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA,
                                           self.resident_sets, scale, st),
               "fetch_kv_attn_inplace")
+        self._fetch_event(ev0, layer_idx)
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
         check(L.skv_attn_finish_inplace(ptr(ws), ptr(self.cnts), ptr(out), bs, Hq, self.num_key_value_heads,
                                         self.select_sets, SA, st), "attn_finish_inplace")

@@ -137,14 +137,33 @@ class DecoderLM:
 
     # --------------------------------------------------------------- per-layer pieces (llama.py:283-427)
     def pre_attention_compute(self, hidden_states, layer):
-        hs = tensor_op.layer_norm(hidden_states, layer.input_layernorm_variance_epsilon, layer.input_layernorm_weight)
-        qkv = F.linear(hs, layer.wqkv, layer.bqkv)
+        """RMSNorm -> fused QKV projection -> split (llama.py:283-303).  One decode token per sequence takes the native
+        kernels (norm in the GEMV's prologue at bs 1, the rows GEMM for 2..32 sequences); prefill-sized inputs F.linear."""
+        if hidden_states.shape[1] == 1 and hidden_states.is_cuda:
+            _, qkv = tensor_op.norm_linear_decode(hidden_states, None, layer.input_layernorm_weight,
+                                                  layer.input_layernorm_variance_epsilon, layer.wqkv, layer.bqkv)
+        else:
+            hs = tensor_op.layer_norm(hidden_states, layer.input_layernorm_variance_epsilon, layer.input_layernorm_weight)
+            qkv = F.linear(hs, layer.wqkv, layer.bqkv)
         q, k, v = qkv.split([layer.q_size, layer.kv_size, layer.kv_size], dim=-1)
         return q, k, v.view(v.shape[0], -1, self.num_key_value_heads, self.head_dim).transpose(1, 2)
 
     def apply_rotary_pos_emb(self, q, k, position_ids):
         """q [bs, s, Hq*D], k [bs, s, Hkv*D] -> [bs, H, s, D] rotated at position_ids [bs, s]."""
         bs, s = q.shape[0], q.shape[1]
+        n_fused = (self.num_heads + 2 * self.num_key_value_heads) * self.head_dim
+        if (s == 1 and q.is_cuda and q.stride(-1) == 1 and q.stride(0) == n_fused and k.stride(0) == n_fused
+                and q.untyped_storage().data_ptr() == k.untyped_storage().data_ptr()
+                and k.storage_offset() - q.storage_offset() == self.num_heads * self.head_dim):
+            # one decode token: q and k are the split views of the fused projection's output (pre_attention_compute) - ONE
+            # native launch rotates both (the kernel of the fused step, its cache-push half pointed at a one-row scratch)
+            qkv = q.as_strided((bs, 1, n_fused), (n_fused, n_fused, 1))
+            kr = torch.empty(bs, self.num_key_value_heads, 1, self.head_dim, dtype=q.dtype, device=q.device)
+            if getattr(self, "_row0", None) is None:
+                self._row0 = torch.zeros(1, dtype=torch.long, device=q.device)
+            qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, self._row0, kr, torch.empty_like(kr),
+                                           self.num_heads, self.num_key_value_heads)
+            return qr, kr
         q = q.view(bs, s, self.num_heads, self.head_dim).transpose(1, 2)
         k = k.view(bs, s, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         if self.cfg.rope_style == "neox":
@@ -163,6 +182,13 @@ class DecoderLM:
         return torch.cat((out, xp), dim=-1).contiguous()
 
     def post_attention_compute(self, attn_output, residual, layer):
+        """o-projection + residual -> RMSNorm -> gate/up -> SiLU*mul -> down + residual (llama.py:405-427)."""
+        if attn_output.shape[1] == 1 and attn_output.is_cuda:       # one decode token per sequence: native kernels
+            o = tensor_op.linear_decode(attn_output, layer.wo)
+            residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
+                                                         layer.post_attention_layernorm_variance_epsilon,
+                                                         layer.gate_up_proj, fuse_silu_mul=True)
+            return residual + tensor_op.linear_decode(act, layer.down_proj)
         hs = residual + F.linear(attn_output, layer.wo)
         residual = hs
         hs = tensor_op.layer_norm(hs, layer.post_attention_layernorm_variance_epsilon,
@@ -249,6 +275,9 @@ class DecoderLM:
         hs = F.embedding(input_ids, self.embed_tokens)
         for idx in range(self.num_layers):
             hs = self.layer_compute(self.layers[idx], idx, hs, position_ids)
+        if hs.shape[1] == 1 and hs.is_cuda:
+            _, logits = tensor_op.norm_linear_decode(hs, None, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
+            return logits.float()
         hs = tensor_op.layer_norm(hs, self.norm_variance_epsilon, self.norm_weight)
         return F.linear(hs, self.lm_head).float()
 
@@ -332,8 +361,9 @@ def build_synthetic_context_full(model, context_len, seed=1234):
     for l in range(model.num_layers):
         g = torch.Generator(device=model.device).manual_seed(seed + l)
         for t in (c.k_cache, c.v_cache):
-            t[l][:, :, :context_len].copy_(torch.randn(t[l][:, :, :context_len].shape, device=model.device,
-                                                       generator=g).to(model.dtype))
+            for b in range(t.shape[1]):          # one sequence at a time: the f32 temporary stays at 0.5 GB whatever the batch
+                t[l][b, :, :context_len].copy_(torch.randn(t[l][b, :, :context_len].shape, device=model.device,
+                                                           generator=g).to(model.dtype))
     c.kv_offset = context_len
     torch.cuda.synchronize(model.device)
 
@@ -383,8 +413,13 @@ class GraphDecoder:
     At bs = 1 a decode step is ~25 launches per layer; eager PyTorch is host-bound on that
     (MI355X_MICROARCH.md "graph-replay-floor"), the graph removes the per-launch host cost."""
 
-    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None, seed=1234, ring_slack=False):
+    NATIVE_SAMPLER_MAX_VOCAB = 4 * 131072     # skv_sample_topk_advance: rows are searched in parts of <= 131,072 logits
+
+    def __init__(self, model, temperature=0.6, top_p=0.9, top_k=50, walk_table=None, seed=1234, ring_slack=False,
+                 allow_torch_topk_capture=False):
         self.m = model
+        self.allow_torch_topk_capture = bool(allow_torch_topk_capture)
+        self._capturing = False
         self.ring_slack = bool(ring_slack)
         self.seed = int(seed)
         self.temperature, self.top_p, self.top_k = temperature, top_p, top_k
@@ -410,9 +445,10 @@ class GraphDecoder:
         self.hit_accum = torch.zeros(1, dtype=torch.long, device=dev)
 
     def _sample(self, logits):
-        """Same distribution as tensor_op.sample_token (top-k 50 -> top-p 0.9 -> multinomial): after the top-k
-        filter every other logit is -inf, so the nucleus is found among the k sorted survivors instead of sorting
-        the whole vocabulary (128K floats).  No host-side checks: graph-capturable."""
+        """tensor_op.sample_token's pipeline (top-k 50 -> top-p 0.9 -> multinomial) on the k sorted survivors of
+        torch.topk instead of a sort of the whole vocabulary.  Differs from the reference on rows with ties at the k-th
+        value: torch.topk keeps exactly k, the reference's filter (tensor_op.py:253-255) and the native sampler keep
+        every logit tied with the k-th.  No host-side checks: graph-capturable (see _body for the bs > 1 guard)."""
         if self.temperature == 0.0:
             return logits.argmax(dim=-1, keepdim=True)
         k = min(self.top_k, logits.size(-1)) if self.top_k > 0 else logits.size(-1)
@@ -427,7 +463,7 @@ class GraphDecoder:
 
     @staticmethod
     def _topk(x, k, parts=64):
-        """torch.topk(x, k, dim=-1) for rows the native sampler does not take (vocabulary > 131,072: GLM-4).  Large
+        """torch.topk(x, k, dim=-1) for rows the native sampler does not take (vocabulary > 524,288, k > 64, f32 logits).  Large
         rows always go through two levels of SHORT-slice top-k (top-k of each of `parts` slices, then top-k of the
         parts * k survivors - the global top-k is a subset of them): PyTorch's multi-block top-k over long slices faulted
         under hipGraph replay on this ROCm build (round 1: bs > 1 over 128,256 logits), short slices take its single-block
@@ -463,7 +499,8 @@ class GraphDecoder:
         k = min(self.top_k, V) if self.top_k > 0 else V
         tlen = self.walk_table.shape[0] if self.walk_table is not None else 1
         if (self.temperature > 0.0 and k <= 64 and last.is_cuda and last.dtype == torch.bfloat16 and V % 8 == 0
-                and V <= 131072 and last.stride(-1) == 1 and last.stride(0) % 8 == 0 and last.data_ptr() % 16 == 0):
+                and V <= self.NATIVE_SAMPLER_MAX_VOCAB and last.stride(-1) == 1 and last.stride(0) % 8 == 0
+                and last.data_ptr() % 16 == 0):
             # ONE native launch from the bf16 logits: exact top-k, temperature, top-p, draw, every counter of the step
             check(lib().skv_sample_topk_advance(ptr(last), last.stride(0), V, last.shape[0], k, float(self.temperature),
                                                 float(self.top_p), self.seed, ptr(self.token), ptr(self.pos), ptr(self.gen),
@@ -472,6 +509,13 @@ class GraphDecoder:
                                                 self.slack, tlen, *self._hit_args(), current_stream_handle()),
                   "sample_topk_advance")
             return
+        # Not taken by any BASELINE configuration (GLM-4's 151,552 logits are native since round 3).  torch.topk's
+        # multi-block path faulted under hipGraph replay in round 1 (profiles/r02_graph_fault_record.txt): a captured
+        # step with bs > 1 must not reach it unless the caller asks for it.
+        if self._capturing and last.shape[0] > 1 and not self.allow_torch_topk_capture:
+            raise RuntimeError("the native sampler does not take this logit row (vocabulary %d, top_k %d, dtype %s) and the "
+                               "torch.topk fallback must not be captured at bs > 1 (GPU fault under hipGraph replay in round 1);"
+                               " GraphDecoder(allow_torch_topk_capture=True) overrides" % (V, k, last.dtype))
         last = last.float()
         if self.temperature > 0.0 and k <= 64 and last.is_cuda:
             # top-k by torch, then ONE native launch: top-p filter, draw, and every device-side counter of the step
@@ -521,8 +565,15 @@ class GraphDecoder:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize(self.m.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
-            self._body()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(self.graph, stream=s):
+                self._body()
+        except Exception:
+            self.graph = None
+            raise
+        finally:
+            self._capturing = False
         return warmup
 
     @torch.inference_mode()

@@ -252,7 +252,9 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     if splits is None:
         # one workgroup per (kv head, split): fill the 256 CUs (profiles/r02_attn_mfma_probe.txt: 64 splits beat 32 for
         # 4 KV heads); the combine kernel merges up to 62 records
-        splits = max(1, min(60, 256 // max(1, bs * Hkv)))
+        # long rows (full-attention baseline: 125 K keys per head) get a split per ~2 K keys whatever the batch, so that
+        # every CU holds several workgroups
+        splits = max(1, min(60, max(256 // max(1, bs * Hkv), -(-rows // 2048))))
     ws = attention_workspace(q.device, bs, Hq, splits)
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)

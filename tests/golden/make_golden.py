@@ -147,7 +147,7 @@ def run_case(ref, case):
 # else that is large is reduced to a SHA-256 digest `h_<name>` (byte-exact comparisons only).
 KEEP_FULL = {
     "llama_small": {"svd_U", "svd_SV", "lm", "ksparse0", "cpu_lm"},
-    "llama_cpu_b1024": set(),
+    "llama_cpu_b1024": {"lm"},
     "glm_small": {"svd_U", "svd_SV", "lm", "ksparse0"},
 }
 SMALL = 64 * 1024

@@ -476,27 +476,49 @@ def test_sample_advance_kernel_distribution_and_counters():
     assert (draws[:, 1] - 1050).max() <= 3
 
 
+@pytest.mark.parametrize("case", ["bs2_vocab128256", "bs2_glm_vocab151552", "bs8_headline_shapes_122k"])
 @torch.inference_mode()
-def test_captured_batch2_full_vocabulary_replays_like_eager():
-    """The mode that faulted in round 1: a CAPTURED decode step with bs = 2 over the real vocabulary (128,256 logits per
-    sequence, sampling at temperature 0.6 with the two-level top-k) replayed several times.  Tokens, chunk bookkeeping
-    and cache bytes must equal the eager run of the same step function from the same state (the sampler is counter-based:
-    same seed and positions -> same draws)."""
+def test_captured_batched_step_replays_like_eager(case):
+    """The mode that faulted in round 1: a CAPTURED decode step with bs > 1 over the real vocabulary, sampling at temperature
+    0.6, replayed several times.  Tokens, chunk bookkeeping and cache bytes must equal the eager run of the same step
+    function from the same state (the sampler is counter-based: same seed and positions -> same draws).  The sampler is the
+    native kernel in every case (no torch.topk in the captured step):
+      * bs 2, 128,256 logits per sequence (Llama-3.1);
+      * bs 2, GLM-4 shapes: 151,552 logits (searched in two parts), 4 KV heads x 8 query heads, GLM RoPE, QKV bias;
+      * bs 8 at the headline shapes: 124,928-token context, budget 2048, 8 KV heads (2 layers): the batch regime of
+        bench.py's `batched` lines (plain fetch launch + standalone attention, rows GEMM for 8 token rows)."""
     from shadowkv_amd import llama
-    cfg = llama.ModelConfig(name="wide-vocab", hidden_size=4096, intermediate_size=2048, num_hidden_layers=2,
-                            num_attention_heads=32, num_key_value_heads=8, vocab_size=128256)
+    if case == "bs2_vocab128256":
+        cfg = llama.ModelConfig(name="wide-vocab", hidden_size=4096, intermediate_size=2048, num_hidden_layers=2,
+                                num_attention_heads=32, num_key_value_heads=8, vocab_size=128256)
+        batch, ctx, budget = 2, 4608, 256
+    elif case == "bs2_glm_vocab151552":
+        cfg = llama.ModelConfig(name="glm-vocab", hidden_size=4096, intermediate_size=2048, num_hidden_layers=2,
+                                num_attention_heads=32, num_key_value_heads=4, vocab_size=151552, qkv_bias=True,
+                                rope_style="glm", rope_theta=1e8)
+        batch, ctx, budget = 2, 4608, 256
+    else:
+        cfg = llama.ModelConfig(name="headline-2-layers", num_hidden_layers=2)          # Llama-3.1-8B shapes otherwise
+        batch, ctx, budget = 8, 122 * 1024, 2048
 
     def make():
-        m = llama.DecoderLM(cfg=cfg, batch_size=2, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
-                            seed=5, chunk_layout="inplace", overlap_attention=True)
-        llama.build_synthetic_context(m, 4608, seed=77)
+        m = llama.DecoderLM(cfg=cfg, batch_size=batch, max_length=ctx, device=DEV, sparse_budget=budget, rank=160,
+                            chunk_size=8, seed=5, chunk_layout="inplace", overlap_attention=True)
+        llama.build_synthetic_context(m, ctx, seed=77)
         return m
-    steps, tok0 = 7, torch.tensor([[17], [4242]], device=DEV)
+    steps = 7
+    tok0 = (torch.arange(batch, device=DEV).view(-1, 1) * 4211 + 17) % cfg.vocab_size
     m1 = make()
     d1 = llama.GraphDecoder(m1, temperature=0.6, seed=99)           # never captured: every step eager
     d1.token.copy_(tok0)
     t1 = [d1.step().flatten().tolist() for _ in range(steps)]
     torch.cuda.synchronize()
+    c1 = m1.kv_cache
+    st1 = (c1.kv_offset, c1.gen_offset, c1.position_ids.clone(), c1.k_cache_buffer.view(torch.int16).clone(),
+           c1.v_cache_buffer.view(torch.int16).clone(), d1.pos.clone(), d1.kv_len.clone(), d1.gen.clone())
+    del m1, d1, c1
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     m2 = make()
     d2 = llama.GraphDecoder(m2, temperature=0.6, seed=99)
     d2.token.copy_(tok0)
@@ -505,12 +527,26 @@ def test_captured_batch2_full_vocabulary_replays_like_eager():
     torch.cuda.synchronize()
     assert d2.graph is not None
     assert t2 == t1[warm:], (t1, t2)
-    c1, c2 = m1.kv_cache, m2.kv_cache
-    assert c1.kv_offset == c2.kv_offset and c1.gen_offset == c2.gen_offset == steps
-    assert torch.equal(c1.position_ids, c2.position_ids)
-    assert torch.equal(c1.k_cache_buffer.view(torch.int16), c2.k_cache_buffer.view(torch.int16))
-    assert torch.equal(c1.v_cache_buffer.view(torch.int16), c2.v_cache_buffer.view(torch.int16))
-    assert torch.equal(d1.pos, d2.pos) and torch.equal(d1.kv_len, d2.kv_len) and torch.equal(d1.gen, d2.gen)
+    c2 = m2.kv_cache
+    assert st1[0] == c2.kv_offset and st1[1] == c2.gen_offset == steps
+    assert torch.equal(st1[2], c2.position_ids)
+    assert torch.equal(st1[3], c2.k_cache_buffer.view(torch.int16))
+    assert torch.equal(st1[4], c2.v_cache_buffer.view(torch.int16))
+    assert torch.equal(st1[5], d2.pos) and torch.equal(st1[6], d2.kv_len) and torch.equal(st1[7], d2.gen)
+    # the selection did real work in the last step: some chunks hit, some fetched over PCIe
+    hits = c2._cnts_layers.sum().item()
+    assert 0 < hits < c2.block_num * c2.select_sets * m2.num_layers
+
+
+@torch.inference_mode()
+def test_capture_refuses_the_torch_topk_fallback_at_batch_2():
+    """A logit row the native sampler does not take (top_k > 64) would put torch.topk into the captured step; at bs > 1
+    that is the launch sequence that faulted in round 1: capture() raises instead (unless explicitly allowed)."""
+    m, llama = _make(layout="inplace", batch=2)
+    d = llama.GraphDecoder(m, temperature=0.6, top_k=100)
+    with pytest.raises(RuntimeError, match="torch.topk fallback"):
+        d.capture(warmup=1)
+    assert d.graph is None
 
 
 @torch.inference_mode()
@@ -558,13 +594,13 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
     from shadowkv_amd import _lib
     L = _lib.lib()
     g = torch.Generator(device=DEV).manual_seed(11)
-    for V in (128256, 32000, 1000 * 8):
+    for V in (128256, 151552, 262144, 32000, 1000 * 8):        # (151,552 = GLM-4: searched in two parts, merged)
         bs, k = 4, 50
         x = (torch.randn(bs, V, device=DEV, generator=g) * 2).bfloat16()
         x[0, 777] = 30.0                                      # row 0: one dominant logit
         x[2] = -x[2].abs() - 1                                # row 2: every logit negative
         x[3] = 1.5                                            # row 3: every logit equal (the prefilter finds V candidates:
-        token = torch.zeros(bs, 1, dtype=torch.long, device=DEV)   # full-row path; winners = the k lowest token ids)
+        token = torch.zeros(bs, 1, dtype=torch.long, device=DEV)   # full-row path; winners = the 64 lowest token ids)
         pos = torch.tensor([[5], [6], [7], [8]], dtype=torch.long, device=DEV)
         gen = torch.tensor([3], dtype=torch.long, device=DEV); row = torch.zeros(1, dtype=torch.long, device=DEV)
         kvl = torch.zeros(1, dtype=torch.int32, device=DEV)
@@ -591,7 +627,7 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
             allowed = set(ti[b_].tolist()) | set((xf[b_] == kth).nonzero().flatten().tolist())
             assert set(draws[:, b_].tolist()) <= allowed, (V, b_)
         assert torch.all(draws[:, 0] == 777)                  # p0 > top_p: the nucleus is the dominant token alone
-        assert int(draws[:, 3].max()) < k and len(set(draws[:, 3].tolist())) > 20   # ties -> lowest ids; uniform draw
+        assert int(draws[:, 3].max()) < 64 and len(set(draws[:, 3].tolist())) > 20  # all tied: the 64 lowest ids; uniform draw
         # row 1: expected nucleus from torch ops (unique values among the leaders of a randn row at this size)
         p = torch.softmax(tv[1] / 0.6, dim=-1)
         keep = torch.cat((torch.ones(1, dtype=torch.bool, device=DEV), torch.cumsum(p, 0)[:-1] <= 0.9))
@@ -605,5 +641,41 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
         assert pos.flatten().tolist() == [5 + 602, 6 + 602, 7 + 602, 8 + 602] and int(gen) == 3 + 602
         assert int(row) == 2496 + (3 + 602) % 96 and int(kvl) == 2496 + 96
     # shapes the kernel is not built for are refused, not mis-sampled
-    assert L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), 151552, 1, 50, 0.6, 0.9, 1, _lib.ptr(token), _lib.ptr(pos),
+    assert L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), 4 * 131072 + 8, 1, 50, 0.6, 0.9, 1, _lib.ptr(token), _lib.ptr(pos),
                                      _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1, 0, 0, 0, 0) == -2
+
+
+@pytest.mark.parametrize("V", [128256, 151552])
+def test_sample_topk_keeps_every_logit_tied_with_the_kth_value(V):
+    """The reference's top-k filter masks logits < the k-th value (models/tensor_op.py:253-255): every logit TIED with the
+    k-th stays in the distribution (torch.topk alone would keep exactly k).  Row: 40 distinct leaders, 20 logits tied at
+    the 50th value scattered over the row (for 151,552 on both sides of the part boundary), the rest lower: all 60 must be
+    drawable, nothing else; with 30 more tied logits than the 64-winner capacity the lowest ids are kept."""
+    from shadowkv_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bs, k = 2, 50
+    x = (torch.rand(bs, V, device=DEV, generator=g) * 2).bfloat16()                 # [0, 2)
+    lead = torch.randperm(V, device=DEV, generator=g)[:40 + 54]
+    for b_ in range(bs):
+        x[b_, lead[:40]] = (3.0 + (torch.arange(40, device=DEV) + 1) / 64.0).bfloat16()
+    tied0 = lead[40:60]
+    tied1 = lead[40:94]                                                             # row 1: 54 tied -> 24 kept (64 - 40)
+    x[0, tied0] = 3.0
+    x[1, tied1] = 3.0
+    token = torch.zeros(bs, 1, dtype=torch.long, device=DEV)
+    pos = torch.tensor([[5], [6]], dtype=torch.long, device=DEV)
+    gen = torch.tensor([3], dtype=torch.long, device=DEV); row = torch.zeros(1, dtype=torch.long, device=DEV)
+    kvl = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = []
+    for _ in range(3000):
+        _lib.check(L.skv_sample_topk_advance(_lib.ptr(x), x.stride(0), V, bs, k, 1.0, 0.0, 99, _lib.ptr(token), _lib.ptr(pos),
+                                             _lib.ptr(gen), _lib.ptr(row), _lib.ptr(kvl), 0, 2496, 96, 1, 0, 0, 0,
+                                             _lib.current_stream_handle()), "sample_topk_advance")
+        out.append(token.flatten().clone())
+    torch.cuda.synchronize()
+    draws = torch.stack(out)
+    want0 = set(lead[:60].tolist())
+    assert set(draws[:, 0].tolist()) == want0                                       # every tied logit drawn, nothing else
+    kept1 = set(lead[:40].tolist()) | set(sorted(tied1.tolist())[:24])
+    assert set(draws[:, 1].tolist()) == kept1

@@ -4,15 +4,14 @@ under the dense GEMVs for free?  Stream A: gate/up-shaped GEMVs over HBM-cold we
 import sys, torch
 sys.path.insert(0, ".")
 from shadowkv_amd import _lib
-from shadowkv_amd.kv_cache import _PinnedHostBuffer
+from shadowkv_amd.kv_cache import pinned_host_tensor
 L = _lib.lib(); dev = "cuda:0"
 chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 heads, table = 8, 15616
 N, K = 28672, 4096
 ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(8)]
 x = torch.randn(1, K, device=dev).bfloat16(); y = torch.empty(1, N // 2, device=dev, dtype=torch.bfloat16)
-hostbuf = _PinnedHostBuffer(heads * table * 2048)
-vhost = hostbuf.tensor((1, heads, table, 1024), torch.bfloat16); vhost.normal_()
+vhost = pinned_host_tensor((1, heads, table, 1024), torch.bfloat16); vhost.normal_()
 vdev = torch.zeros(1, heads, chunks, 1024, device=dev, dtype=torch.bfloat16)
 ids = torch.stack([torch.randperm(table)[:chunks] for _ in range(heads)]).view(1, heads, chunks).to(dev)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
