@@ -464,6 +464,16 @@ def rank_record(rank, local_rank, model, head, t_build, numa_gpu):
     return rec
 
 
+def gather_rank_records(my_rec, world):
+    """Every rank's record on every rank (all_gather_object over the job's process group; world 1: no collective)."""
+    if world <= 1:
+        return [my_rec]
+    import torch.distributed as dist
+    recs = [None] * world
+    dist.all_gather_object(recs, my_rec)
+    return sorted(recs, key=lambda r: r["rank"])
+
+
 def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
     """PCIe rate INSIDE the fetch launch (K rebuild || V fetch [|| attention]): a few eager decode steps with a pair of
     events around every layer's fetch launch; bytes = the miss chunks of exactly those launches (per-layer hit counts)."""
@@ -608,10 +618,7 @@ def main():
 
     # one diagnostic record per rank, gathered to rank 0 (no effect on the timed region above)
     my_rec = rank_record(rank, local_rank, model, head, t_build, numa)
-    per_rank = [my_rec]
-    if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, my_rec)
+    per_rank = gather_rank_records(my_rec, world)
 
     if rank == 0:
         extras = {}

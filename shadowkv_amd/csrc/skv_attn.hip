@@ -143,12 +143,9 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
                         (G == 8 && !slots ? SKV_ATTN_MFMA_LDS_FLOATS * sizeof(float) : 0);
 #define SKV_AT_L(GG, LL)                                                                                        \
     do {                                                                                                        \
-        static size_t attr_bytes = 0;                                                                           \
-        if (smem > 64 * 1024 && smem > attr_bytes) {                                                            \
-            (void)hipFuncSetAttribute((const void*)skv_attn_partial_kernel<GG, LL>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
-            attr_bytes = smem;                                                                                  \
-        }                                                                                                       \
+        static size_t attr_bytes[64] = {};                                                                      \
+        if (skv_ensure_max_lds((const void*)skv_attn_partial_kernel<GG, LL>, smem, attr_bytes) != SKV_OK)       \
+            return SKV_ERR_LAUNCH;                                                                              \
         hipLaunchKernelGGL((skv_attn_partial_kernel<GG, LL>), grid, block, smem, st, (const bf16_t*)q,          \
                            (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows,    \
                            kv_stride_h, Hkv, splits, scale, slots, n_slots, sparse_start, resident_rows);       \

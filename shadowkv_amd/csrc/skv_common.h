@@ -207,6 +207,18 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: launchers that need more than 64 KB of
+// dynamic LDS remember what they have set per device (a process may drive several GPUs), not in one process-wide flag.
+// `set_bytes`: a zero-initialised static array of the call site.  Returns 0 or SKV_ERR_LAUNCH (-3).
+static inline int skv_ensure_max_lds(const void* fn, size_t bytes, size_t (&set_bytes)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (bytes <= 64 * 1024 || bytes <= set_bytes[dev]) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -3;
+    set_bytes[dev] = bytes;
+    return 0;
+}
+
 // error codes of the C ABI
 #define SKV_OK 0
 #define SKV_ERR_ARG (-1)

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
     // block -> (role index bx, batch*head by).  Attention role present: a 1-D grid in which the tile blocks (from the
     // highest tile index down, all heads of a tile index together: the live tiles - miss chunks - are the last indices
     // and are the long pole, their host loads should go out at once) are INTERLEAVED with the split-attention blocks over
-    // the resident rows in the ratio of their counts.  One 512-thread workgroup fits per CU, blocks get CUs in id order:
+    // the resident rows in the ratio of their counts.  One 512-thread workgroup runs per CU (the launcher asks for > 80 KB
+    // of LDS; __launch_bounds__(512, 2) = two waves per SIMD = that one workgroup), blocks get CUs in id order:
     // with all tiles first, a batch with more live tiles than CUs (bs >= 3 at 67 % hits) would start the attention blocks
     // only after the PCIe-bound tiles had drained and lose the overlap.
     int bx = blockIdx.x, by = blockIdx.y;
@@ -391,8 +392,10 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
     u32x4 afrag[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) afrag[ks] = *reinterpret_cast<const u32x4*>(urow + 32 * ks);
-    // SV[b][h] -> registers (stored to LDS below); with the attention role the staging goes in two halves to keep the
-    // kernel at 128 VGPRs (two 512-thread workgroups per CU: while one waits on PCIe the other's loads are in flight)
+    // SV[b][h] -> registers (stored to LDS below); with the attention role the staging goes in two halves (128 VGPRs instead
+    // of ~170).  That was written for two 512-thread workgroups per CU; measured (38.1 vs 36.4 us, see the launcher) ONE
+    // workgroup per CU is faster - the launcher's LDS request enforces it - and the half staging stayed because it costs
+    // nothing there (the second half's loads are in flight while the first half is written to LDS).
     constexpr int SV_HALF = AG > 0 ? (SV_ITERS + 1) / 2 : SV_ITERS;
     u32x4 svreg[SV_HALF];
     const u32x4* const sv_src = reinterpret_cast<const u32x4*>(SV + (size_t)bh * RB_D * R);
@@ -588,12 +591,9 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
     if (attn) {
 #define SKV_RBA(M, GG)                                                                                             \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set && smem_all > 64 * 1024) {                                                                   \
-            (void)hipFuncSetAttribute((const void*)skv_rebuild_kernel<M, 5, GG>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_all);                  \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
+        static size_t attr_bytes[64] = {};                                                                         \
+        if (skv_ensure_max_lds((const void*)skv_rebuild_kernel<M, 5, GG>, smem_all, attr_bytes) != SKV_OK)         \
+            return SKV_ERR_LAUNCH;                                                                                 \
         hipLaunchKernelGGL((skv_rebuild_kernel<M, 5, GG>), grid, block, smem_all, st, (const bf16_t*)U,            \
                            (const bf16_t*)SV, (const bf16_t*)cos_sin, ids, cnts, (bf16_t*)out, heads, seq_len, S, C, \
                            ids64, cs_stride, out_stride_b, out_stride_h, out_stride_s, out_row0,                   \

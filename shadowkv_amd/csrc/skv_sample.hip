@@ -350,15 +350,6 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     }
 }
 
-// MaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one flag per (kernel, device)
-static bool attr_needed(bool (&done)[64]) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    if (done[dev]) return false;
-    done[dev] = true;
-    return true;
-}
-
 template <int SEGV>
 static int launch_sample_topk(const void* logits, long long row_stride, int V, int parts, int part_len, int bs, int k,
                               float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
@@ -366,12 +357,8 @@ static int launch_sample_topk(const void* logits, long long row_stride, int V, i
                               long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
                               int64_t* hit_accum, hipStream_t st) {
     const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3 + SMP_CAND + 2 * SMP_PARTS * SMP_KEEP) * sizeof(int);
-    static bool attr_set[64] = {};
-    if (attr_needed(attr_set)) {
-        if (hipFuncSetAttribute((const void*)skv_sample_topk_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return SKV_ERR_LAUNCH;
-    }
+    static size_t attr_bytes[64] = {};
+    if (skv_ensure_max_lds((const void*)skv_sample_topk_kernel<SEGV>, smem, attr_bytes) != SKV_OK) return SKV_ERR_LAUNCH;
     hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
                        V, parts, part_len, k, temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
                        table_len, hit_cnts, n_hit_cnts, hit_accum);

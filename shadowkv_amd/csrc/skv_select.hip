@@ -33,7 +33,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SKV_SCORE_WAVES 16                      // waves per 256-landmark tile (16 rows each; 4/8/16 measured: 9.3 / 8.8 / 8.5 us)
 #endif
 #ifndef SKV_SCORE_PD
-#define SKV_SCORE_PD 2                          // row-group loads a wave keeps in flight (see the kernel comment)
+#define SKV_SCORE_PD 64                         // row-group loads a wave keeps in flight; >= ITERS: all up front (see the kernel comment)
 #endif
 // One row group (4 landmark rows of one wave-instruction) against GH query heads held in registers: per-lane fma chain over
 // the lane's 8 elements (two heads per v_pk_fma_f32), transposing 16-lane butterfly, one bf16 logit per lane into the tile.
@@ -64,18 +64,21 @@ __device__ __forceinline__ void score_row_group(const f32x2 (&qf)[(GH + 1) / 2][
 // ABL (ablation, diagnostic builds only - tools/score_probe.hip): 0 = the kernel; 1 = loads only (no dot
 // products); 2 = no per-tile statistics tail.  The library instantiates ABL = 0 only.
 //
-// Round 3: (1) the loads of a wave are PIPELINED (PD row groups in flight, the next one is requested when the oldest has
-// arrived) instead of all 64 KB of a tile being requested in the first microsecond.  The memory system serves requests
-// roughly in arrival order, so with everything requested up front the workgroups dispatched last received their whole tile
-// last and then still had all of its arithmetic to do, exposed, while the early workgroups' CUs idled: the kernel took
-// "loads only" + the arithmetic of one or two tiles per CU (6.4 + 1.6 us at G = 4, tools/score_probe.hip).  With a bounded
-// depth per wave a CU that holds two tiles also draws twice the bandwidth of a CU that holds one, so the 400-488 tiles of
-// a launch finish together whatever 256 does to their count.  (2) More than 4 query heads per KV head (GLM: 8) run as
-// PASSES of 4 over the SAME landmark registers: the q fragment of 8 heads alone was 64 VGPRs (100-120 in all, 8 waves per
-// tile, two tiles per CU at best); a pass needs 32, the kernel stays at 64 VGPRs and 16 waves per tile like G = 4.  The later
-// passes' query heads wait in a wave-private LDS copy (no barrier).  Results are bit-identical: every head's total is the
-// same fma chain and the same 16-lane tree whichever other heads travel through the butterfly with it.
-template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES), int PD = (G == 8 ? 3 : SKV_SCORE_PD)>
+// WAVES per tile: 16 for G <= 4 (4 / 8 / 16 waves: 9.3 / 8.8 / 8.5 us), 8 for G = 8 (GLM): its q fragment alone is 64 VGPRs,
+// 108 in all - with 16 waves only ONE workgroup fits a CU (measured 11.1 vs 9.5 us at the 200K shape); 8 waves fit twice.
+// PD = row-group requests a wave keeps in flight (the next one goes out when the oldest has arrived); PD >= ITERS = every
+// request up front, the default.  Round-3 probe (tools/score_probe.hip, profiles/r03_score_probe.txt): a bounded depth
+// changes nothing (G = 4: 7.75 us up front, 8.2 / 7.7 at depth 2 / 3; G = 8: 9.49 up front, 9.45 at depth 3), i.e. the
+// exposed arithmetic is not a late-workgroup effect of first-come-first-served memory service.  The kernel is the
+// loads-only time (6.0 us = 5.3 TB/s at G = 4, 5.55 us at G = 8: the HBM rate of a one-wave launch) plus what cannot
+// overlap it: the row groups that arrive last (every wave's last request completes near the end of the stream) and the
+// per-tile statistics behind the barrier (+1.2 +0.5 us at G = 4; +2.4 +1.5 us at G = 8, where the 144 CUs that hold two
+// of the 400 tiles have 3.4 us of VALU work to fit under a 5.5 us stream).
+// More than 8 query heads per KV head run as PASSES of 4 over the SAME landmark registers (G = 16 spilled 147 scratch
+// operations as one pass): the later passes' query heads wait in a wave-private LDS copy (no barrier).  Results are
+// bit-identical: every head's total is the same fma chain and the same 16-lane tree whichever other heads travel through
+// the butterfly with it.
+template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES), int PD = SKV_SCORE_PD>
 __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void skv_score_tile_kernel(
     const bf16_t* __restrict__ q,    // [B][G][128]
     const bf16_t* __restrict__ lm,   // [B][N][128]
@@ -1105,13 +1108,10 @@ static int launch_topk2(const void* score, int score_stride, const int64_t* lm_i
                         int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
                         int SP, int R, int RP, int32_t* slot_age, hipStream_t st) {
     const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 5 + RP + H * 2 + 80 + 16) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)skv_topk2_kernel<SEGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96) * sizeof(int))) != hipSuccess)
-            return SKV_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static size_t attr_bytes[64] = {};
+    if (skv_ensure_max_lds((const void*)skv_topk2_kernel<SEGV>, (size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96) * sizeof(int),
+                           attr_bytes) != SKV_OK)
+        return SKV_ERR_LAUNCH;
     hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
                        cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age);
     return SKV_OK;
@@ -1141,13 +1141,9 @@ int skv_launch_topk_resident(const void* score, int score_stride, const int64_t*
     const bool stage = score != nullptr && with_score <= 150 * 1024;
     const size_t smem = stage ? with_score : base;
     if (stage) {
-        static size_t attr_bytes = 0;
-        if (smem > 64 * 1024 && smem > attr_bytes) {
-            if (hipFuncSetAttribute((const void*)skv_topk_reorder_kernel<1>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return SKV_ERR_LAUNCH;
-            attr_bytes = 150 * 1024;
-        }
+        static size_t attr_bytes[64] = {};
+        if (smem > 64 * 1024 && skv_ensure_max_lds((const void*)skv_topk_reorder_kernel<1>, 150 * 1024, attr_bytes) != SKV_OK)
+            return SKV_ERR_LAUNCH;
         hipLaunchKernelGGL(skv_topk_reorder_kernel<1>, dim3(B), dim3(SKV_SEL_THREADS), smem, st,
                            (const bf16_t*)score, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, N,
                            score_stride, S, H, SP);

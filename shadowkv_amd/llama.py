@@ -512,7 +512,7 @@ class GraphDecoder:
         # Not taken by any BASELINE configuration (GLM-4's 151,552 logits are native since round 3).  torch.topk's
         # multi-block path faulted under hipGraph replay in round 1 (profiles/r02_graph_fault_record.txt): a captured
         # step with bs > 1 must not reach it unless the caller asks for it.
-        if self._capturing and last.shape[0] > 1 and not self.allow_torch_topk_capture:
+        if self.temperature > 0.0 and self._capturing and last.shape[0] > 1 and not self.allow_torch_topk_capture:
             raise RuntimeError("the native sampler does not take this logit row (vocabulary %d, top_k %d, dtype %s) and the "
                                "torch.topk fallback must not be captured at bs > 1 (GPU fault under hipGraph replay in round 1);"
                                " GraphDecoder(allow_torch_topk_capture=True) overrides" % (V, k, last.dtype))

@@ -252,6 +252,45 @@ def test_full_attention_baseline_graph_equals_eager_and_torch():
 
 
 @torch.inference_mode()
+def test_full_attention_baseline_batch2_against_sdpa_and_captured():
+    """The full-attention baseline at bs = 2 (bench.py's e2e-style pair runs it at the largest batch that fits HBM,
+    /root/reference/test/e2e.py:140-168): the attention over EVERY key of two sequences with different contents against
+    torch SDPA in f32 - at a row length where one (batch, head) is split over many workgroups (20,000 keys -> 10 splits,
+    tensor_op.sparse_attention_decode's long-row rule) - and the captured step against the eager one."""
+    from shadowkv_amd import llama, tensor_op
+    cfg = llama.ModelConfig(name="tiny", hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
+                            num_attention_heads=8, num_key_value_heads=2, vocab_size=2000)
+
+    def make(ctx):
+        m = llama.DecoderLM(cfg=cfg, batch_size=2, max_length=ctx, device=DEV, attn_mode="full", seed=5)
+        llama.build_synthetic_context_full(m, ctx, seed=9)
+        return m
+    m0 = make(20000)
+    c = m0.kv_cache
+    assert not torch.equal(c.k_cache[0][0], c.k_cache[0][1])          # the two sequences hold different keys
+    q = torch.randn(2, 8, 1, 128, device=DEV).bfloat16()
+    out = tensor_op.sparse_attention_decode(q, c.k_cache[0], c.v_cache[0], kv_len=20000)
+    k = c.k_cache[0][:, :, :20000].float().repeat_interleave(4, 1)
+    v = c.v_cache[0][:, :, :20000].float().repeat_interleave(4, 1)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k, v).transpose(1, 2)
+    assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-3), float((out.float() - ref).abs().max())
+    del m0, c, k, v
+    m1, m2 = make(3000), make(3000)
+    tok0 = torch.tensor([[11], [77]], device=DEV)
+    t = tok0.clone(); toks1 = []
+    for _ in range(5):
+        t = m1.decode_step(t, temperature=0.0); toks1.append(t.flatten().tolist())
+    dec = llama.GraphDecoder(m2, temperature=0.0); dec.token.copy_(tok0)
+    warm = dec.capture(warmup=2)
+    toks2 = [dec.step().flatten().tolist() for _ in range(5 - warm)]
+    torch.cuda.synchronize()
+    assert toks2 == toks1[warm:]
+    assert m1.kv_cache.kv_offset == m2.kv_cache.kv_offset == 3005
+    assert torch.equal(m1.kv_cache.k_cache.view(torch.int16), m2.kv_cache.k_cache.view(torch.int16))
+    assert torch.equal(m1.kv_cache.v_cache.view(torch.int16), m2.kv_cache.v_cache.view(torch.int16))
+
+
+@torch.inference_mode()
 def test_batched_decode_matches_single_sequences():
     """bs = 2 through the fused step: every sequence must get exactly what it gets when decoded alone
     (same weights, its own context): tokens, chunk bookkeeping and cache rows."""

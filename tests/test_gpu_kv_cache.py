@@ -7,7 +7,7 @@ import torch
 
 import gen_inputs as G
 import oracle
-from util import ALPHA, assert_bits_equal, ulp_diff_bf16, rope_pair_bound
+from util import ALPHA, assert_bits_equal, ulp_diff_bf16, rope_pair_bound, record_parity, REBUILD_FLIP_BOUND
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -24,7 +24,20 @@ def _build(case):
     cache.prefill_kv_cache(inp["v"].to(DEV), 0, k_roped, inp["q_last"].to(DEV))
     cache.H2D()
     torch.cuda.synchronize()
+    # the V table is page-locked memory of the HIP runtime torch itself uses (skv_host_alloc): torch sees it as pinned, so
+    # copies into it are asynchronous DMA; a slice keeps the allocation alive after the cache is gone
+    assert cache.v_cache_cpu.is_pinned() and not cache.v_cache_cpu.is_cuda
     return cache, c, inp
+
+
+def test_pinned_v_table_outlives_the_cache_through_its_views():
+    import gc
+    cache, c, inp = _build("llama_small")
+    view = cache.v_cache_cpu[0][0, 1]
+    want = view.clone()
+    del cache
+    gc.collect()
+    assert view.is_pinned() and torch.equal(view, want)
 
 
 @pytest.mark.parametrize("case", ["llama_small", "llama_cpu_b1024", "glm_small"])
@@ -88,7 +101,9 @@ def test_decode_steps_match_oracle(case):
             pre, cs, ids32, kb4, cnt, *ints)
         kgpu = cache.k_cache_buffer[0][0].cpu()
         d = ulp_diff_bf16(kbuf, kgpu)
-        assert float((d > 0).sum()) / d.numel() < 0.03, f"step {t}: K buffer"
+        frac, _ = record_parity(f"test_decode_steps_match_oracle[{case}] step {t}", d[:, cache.sparse_start:cache.sparse_end],
+                                "post-RoPE")
+        assert frac < REBUILD_FLIP_BOUND, f"step {t}: K buffer"
         # rebuilt rows: |device - oracle| <= 2^-6 (|x1| + |x2|) per rotation pair (x = the oracle's pre-RoPE row); rows
         # the oracle did not rebuild (hits: pre == 0) must be identical
         kdiff = (kbuf.float() - kgpu.float()).abs()[:, cache.sparse_start:cache.sparse_end]

@@ -26,6 +26,37 @@ def ulp_diff_bf16(a, b):
     return (key(a) - key(b)).abs()
 
 
+# K rebuild (MFMA accumulation order is not restatable on the CPU): fraction of bf16 values allowed to differ from the oracle.
+# Set at 2x the largest fraction measured on MI355X (profiles/r03_rebuild_parity.txt); every differing value is
+# additionally bounded in size by the tests (one pre-RoPE ulp / the rotation-pair bound).
+REBUILD_FLIP_BOUND = 0.03
+
+
+def open_parity_record():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    return open(os.path.join(root, "gpurun_out", "rebuild_parity.txt"), "a")
+
+
+def record_parity(test, d, where="K rebuild"):
+    """Appends the measured disagreement of a tolerance-compared result (d = ulp distances, any shape) to
+    gpurun_out/rebuild_parity.txt: fraction of values that differ, maximum distance in bf16 ulps.  The bounds the tests
+    assert are set from this record (profiles/r03_rebuild_parity.txt).  Returns (fraction, max ulp)."""
+    import os
+    n = d.numel()
+    frac = float((d > 0).sum()) / max(n, 1)
+    mx = int(d.max()) if n else 0
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "rebuild_parity.txt"), "a") as f:
+            f.write(f"{test:72s} {where:14s} values {n:9d}  differing {frac:.6f}  max ulp {mx}\n")
+    except OSError:
+        pass
+    return frac, mx
+
+
 def make_selection_step(gen, n_chunks, S, hit_frac, cached=None):
     """Random resident set + new selection with a given hit fraction (distinct ids)."""
     if cached is None:
