@@ -564,9 +564,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="llama31_122k", choices=list(WORKLOADS))
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer layers (result then marked invalid)")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "call_order"],
                     help="graph: the decode step is captured once into a hipGraph and replayed (default); "
-                         "eager: every launch issued from Python each step")
+                         "eager: every launch issued from Python each step; call_order: the reference's call order "
+                         "(decode_step(fused=False): layer_compute, copy_stream, reference-shaped cache methods), eager")
     ap.add_argument("--batch", type=int, default=1, help="sequences per GPU (headline metric: 1)")
     ap.add_argument("--attn", default="shadowkv", choices=["shadowkv", "full"],
                     help="full: the reference's full-attention baseline (KV_Cache, every key attended) on the same model")
@@ -613,8 +614,16 @@ def main():
     bs = args.batch
     model, cfg, ctx, budget, t_build = build_model(args.workload, args, rank, dev)
     cache = model.kv_cache
-    head = run_decode(model, args, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, world=world,
-                      pin_hit=args.pin_hit_rate)
+    if args.mode == "call_order":
+        if world > 1 or full or bs != 1:
+            print("--mode call_order: one GPU, one sequence, ShadowKV attention", file=sys.stderr)
+            sys.exit(2)
+        r = run_call_order(model, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank)
+        head = dict(value=r["value"], ms_per_step=r["ms_per_step"], hit_rate=r["chunk_hit_rate"], mode="call_order",
+                    slack_ring=False, elapsed_local=r["ms_per_step"] * 1e-3 * args.steps, steps=args.steps)
+    else:
+        head = run_decode(model, args, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, world=world,
+                          pin_hit=args.pin_hit_rate)
 
     # one diagnostic record per rank, gathered to rank 0 (no effect on the timed region above)
     my_rec = rank_record(rank, local_rank, model, head, t_build, numa)

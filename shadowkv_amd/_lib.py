@@ -109,6 +109,16 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream_handle():
+    """hipStream_t of torch's current stream on the current device (what `with torch.cuda.stream(...)` selects)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        # the raw getter skips the Stream object (called ~15 times per layer by the eager paths)
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

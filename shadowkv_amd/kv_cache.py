@@ -378,6 +378,26 @@ class ShadowKVCache_CPU:
                     f"The cache for offloading is not built correctly, {self.position_ids}"
 
     # ------------------------------------------------------------------ decode (native)
+    class _LayerViews:
+        __slots__ = ("kbuf", "vbuf", "vhost", "lm", "lm_idx", "pos", "U", "SV", "cnts", "age")
+
+    def _layer(self, l):
+        """Per-layer views of the state tensors, built once (indexing a tensor makes a new view object every time: ~2 us
+        each, a dozen per layer and step on the eager paths); rebuilt when a parent tensor is replaced."""
+        key = (self.k_cache_buffer, self.v_cache_buffer, self.v_cache_cpu, self.k_landmark, self.k_landmark_idx,
+               self.position_ids, self.U, self.SV)
+        old = getattr(self, "_lv_key", None)
+        if old is None or any(a is not b for a, b in zip(old, key)):        # (the parents themselves are held: no id reuse)
+            self._lv = []
+            for i in range(self.num_layers):
+                v = ShadowKVCache_CPU._LayerViews()
+                v.kbuf, v.vbuf, v.vhost = self.k_cache_buffer[i], self.v_cache_buffer[i], self.v_cache_cpu[i]
+                v.lm, v.lm_idx, v.pos = self.k_landmark[i], self.k_landmark_idx[i], self.position_ids[i]
+                v.U, v.SV, v.cnts, v.age = self.U[i], self.SV[i], self._cnts_layers[i], self._slot_age[i]
+                self._lv.append(v)
+            self._lv_key = key
+        return self._lv[l]
+
     def _gen_rows(self, layer_idx):
         return self.gen_offset if layer_idx == self.num_layers - 1 else self.gen_offset + self.incoming_q_len
 
@@ -387,22 +407,22 @@ class ShadowKVCache_CPU:
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
         self._reference_layout_only("get_retrieval_position_ids")
-        self.cnts = self._cnts_layers[layer_idx]
+        lv = self._layer(layer_idx)
+        self.cnts = lv.cnts
         if self.incoming_q_len != 1:
             raise ValueError("decode-time selection expects q_len == 1 (the reference's top-k over "
                              "view(bs, kv, G, -1) is only meaningful for q_len == 1, kv_cache.py:1023-1035)")
-        lm = self.k_landmark[layer_idx]
+        lm = lv.lm
         n = lm.shape[-2]
         if self._select_ws is None:
             self.H2D()
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
-        check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
-                                      ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self.cnts),
+        check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
                                       ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
                                       self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
               "get_retrieval_position_ids")
         self._stage_hits(layer_idx)
-        return self.position_ids[layer_idx]
+        return lv.pos
 
     def _reference_layout_only(self, what):
         if self.resident_sets != self.select_sets:
@@ -413,7 +433,8 @@ class ShadowKVCache_CPU:
         """Phase 1 of the chunk movement for BOTH buffers of a layer, once per (layer, selection): every hit
         chunk whose slot changes is copied to the staging buffers.  Must run on the stream that produced
         offsets / cnts, before the side stream forks (the fork then orders it before both landings)."""
-        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        lv = self._layer(layer_idx)
+        kbuf, vbuf = lv.kbuf, lv.vbuf
         check(lib().skv_stage_hit_chunks(ptr(kbuf), ptr(self._temp_k), ptr(vbuf), ptr(self._temp_v),
                                          ptr(self.offsets), ptr(self.cnts), kbuf.stride(1),
                                          self.sparse_start * self.head_dim, self.block_num, self.select_sets,
@@ -425,8 +446,8 @@ class ShadowKVCache_CPU:
         hit chunks staged by get_retrieval_position_ids and pulls the misses over PCIe with plain 16-B loads
         (49-56 GB/s measured, the DMA ceiling; tools/pcie_probe.hip)."""
         self._reference_layout_only("get_value_cache")
-        vhost = self.v_cache_cpu[layer_idx]
-        vbuf = self.v_cache_buffer[layer_idx]
+        lv = self._layer(layer_idx)
+        vhost, vbuf = lv.vhost, lv.vbuf
         check(lib().skv_land_chunks(ptr(vhost), ptr(vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
                                     vhost.stride(1), vbuf.stride(1), self.sparse_start * self.head_dim,
                                     self.block_num, self.select_sets, current_stream_handle()), "get_value_cache")
@@ -436,8 +457,9 @@ class ShadowKVCache_CPU:
         """Hit chunks moved to their new slots, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
         region (kv_cache.py:1108-1176), one launch.  `rope_func` is unused, as in the reference."""
         self._reference_layout_only("get_key_cache")
-        kbuf = self.k_cache_buffer[layer_idx]
-        tensor_op.rebuild_keys(self.U[layer_idx], self.SV[layer_idx], cos_sin_cache, position_ids, self.cnts, kbuf,
+        lv = self._layer(layer_idx)
+        kbuf = lv.kbuf
+        tensor_op.rebuild_keys(lv.U, lv.SV, cos_sin_cache, position_ids, self.cnts, kbuf,
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
@@ -598,8 +620,9 @@ class ShadowKVCache_CPU:
         the end of the buffer are dropped exactly as the reference's zero-length slice does."""
         incoming = new_k_cache.shape[-2]
         lo = self.sparse_end + self.gen_offset
-        self.v_cache_buffer[layer_idx][:, :, lo:lo + incoming].copy_(new_v_cache, non_blocking=True)
-        self.k_cache_buffer[layer_idx][:, :, lo:lo + incoming].copy_(new_k_cache, non_blocking=True)
+        lv = self._layer(layer_idx)
+        lv.vbuf[:, :, lo:lo + incoming].copy_(new_v_cache, non_blocking=True)
+        lv.kbuf[:, :, lo:lo + incoming].copy_(new_k_cache, non_blocking=True)
         if layer_idx == self.num_layers - 1:
             self.kv_offset += incoming
             self.gen_offset += incoming

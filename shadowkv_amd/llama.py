@@ -271,13 +271,13 @@ class DecoderLM:
         return torch.arange(past, past + n, device=self.device, dtype=torch.long).unsqueeze(0).repeat(input_ids.size(0), 1)
 
     @torch.inference_mode()
-    def inference(self, input_ids, position_ids):
+    def inference(self, input_ids, position_ids, as_float=True):
         hs = F.embedding(input_ids, self.embed_tokens)
         for idx in range(self.num_layers):
             hs = self.layer_compute(self.layers[idx], idx, hs, position_ids)
         if hs.shape[1] == 1 and hs.is_cuda:
             _, logits = tensor_op.norm_linear_decode(hs, None, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
-            return logits.float()
+            return logits.float() if as_float else logits    # (bf16: tensor_op.sample_token then samples in one launch)
         hs = tensor_op.layer_norm(hs, self.norm_variance_epsilon, self.norm_weight)
         return F.linear(hs, self.lm_head).float()
 
@@ -286,7 +286,7 @@ class DecoderLM:
         """One iteration of the reference's timed loop (base.py:628-635).  fused=False runs the reference's
         exact call order through the reference-shaped methods (inference / layer_compute)."""
         if not fused:
-            logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token))
+            logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token), as_float=False)
         else:
             c = self.kv_cache
             full = self.attn_mode == "full"
@@ -300,7 +300,7 @@ class DecoderLM:
                                    "max_length + max_new_tokens)")
             pos = self.get_ctx(next_token)
             row_idx = torch.tensor([row], device=self.device, dtype=torch.long)
-            logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table)
+            logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table, as_float=False)
             c.note_kv_appended(1)
         return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k)
 

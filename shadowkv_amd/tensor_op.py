@@ -313,7 +313,39 @@ def sample(probs, num_samples=1):
     return torch.multinomial(probs, num_samples=num_samples, replacement=True)
 
 
+_sampler_state = {}
+
+
+def sample_token_native(logits, temperature, top_k, top_p, seed=1234):
+    """sample_token in ONE native launch for bf16 logits [bs, V] on the GPU (skv_sample_topk_advance: exact k-th value,
+    every logit tied with it kept - the reference's filter -, logit / temperature, nucleus, draw).  Same distribution as
+    the torch pipeline below; the random numbers come from a counter-based hash (seed, draw counter, row), not from
+    torch's generator.  Returns None when the kernel does not take the row (caller falls back)."""
+    bs, V = logits.shape
+    k = min(top_k, V) if top_k > 0 else V
+    if not (logits.is_cuda and logits.dtype == torch.bfloat16 and temperature > 0.0 and 1 <= k <= 64 and V % 8 == 0
+            and V <= 4 * 131072 and logits.stride(-1) == 1 and logits.stride(0) % 8 == 0 and logits.data_ptr() % 16 == 0):
+        return None
+    key = (logits.device.index, bs)
+    st = _sampler_state.get(key)
+    if st is None:
+        dev = logits.device
+        st = dict(pos=torch.zeros(bs, 1, dtype=torch.long, device=dev), gen=torch.zeros(1, dtype=torch.long, device=dev),
+                  row=torch.zeros(1, dtype=torch.long, device=dev), kvl=torch.zeros(1, dtype=torch.int32, device=dev))
+        _sampler_state[key] = st
+    token = torch.empty(bs, 1, dtype=torch.long, device=logits.device)
+    check(lib().skv_sample_topk_advance(ptr(logits), logits.stride(0), V, bs, k, float(temperature), float(top_p), seed,
+                                        ptr(token), ptr(st["pos"]), ptr(st["gen"]), ptr(st["row"]), ptr(st["kvl"]), 0, 0, 1, 1,
+                                        0, 0, 0, current_stream_handle()), "sample_topk_advance")
+    return token
+
+
 def sample_token(logits, temperature=0, top_k=50, top_p=0.9):
     if temperature == 0.0:
         return logits.argmax(dim=-1, keepdim=True)
+    if logits.dtype == torch.bfloat16 and logits.is_cuda:     # the lm_head's own output: one native launch
+        tok = sample_token_native(logits, temperature, top_k, top_p)
+        if tok is not None:
+            return tok
+        logits = logits.float()
     return sample(norm_logits(logits, temperature=temperature, top_p=top_p, top_k=top_k))

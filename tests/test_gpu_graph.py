@@ -657,8 +657,13 @@ def test_sample_topk_advance_selects_exactly_and_draws_like_softmax():
         am = run(1, 1.0, 0.0, 2)
         xf = x.float()
         mx = xf.max(dim=-1, keepdim=True).values
-        first_max = torch.where(xf == mx, torch.arange(V, device=DEV).expand(bs, -1), V).min(dim=-1).values
-        assert torch.equal(am[0], first_max) and torch.equal(am[1], first_max)
+        # k = 1: the maximum - every logit tied with it stays (reference filter: logits < the k-th value are removed), so a
+        # row whose maximum is tied draws among the tied ids (the 64 lowest of them when more tie: row 3)
+        for b_ in range(bs):
+            tied = (xf[b_] == mx[b_]).nonzero().flatten()[:64].tolist()
+            assert int(am[0][b_]) in tied and int(am[1][b_]) in tied, (V, b_)
+            if len(tied) == 1:
+                assert int(am[0][b_]) == tied[0] == int(am[1][b_])
         draws = run(k, 0.6, 0.9, 600)
         tv, ti = torch.topk(xf, k, dim=-1)
         for b_ in range(bs):
