@@ -251,6 +251,15 @@ SKV_EXPORT int skv_qkv_rope_update(const void* qkv, const void* cos_sin, const i
 SKV_EXPORT int skv_add_rmsnorm(const void* x, const void* residual, const void* weight, void* h_out, void* y, int rows,
                     int hidden, float eps, skv_stream_t stream);
 
+/* ShadowKVCache_CPU.update_kv_cache (/root/reference/models/kv_cache.py:1227-1271) as one launch: rows [row0, row0 +
+ * incoming) of k_buf / v_buf [bs][heads][buf_rows][128] <- k_new / v_new [bs][heads][incoming][128] (element strides of the
+ * new rows passed: the V rows are a transposed view of the fused projection).  Rows at or past buf_rows are dropped, as the
+ * reference's zero-length slice does. */
+SKV_EXPORT int skv_update_kv_cache(const void* k_new, const void* v_new, void* k_buf, void* v_buf, int batch_size, int heads,
+                        int incoming, int head_dim, long long k_stride_b, long long k_stride_h, long long k_stride_s,
+                        long long v_stride_b, long long v_stride_h, long long v_stride_s, long long buf_stride_b,
+                        long long buf_stride_h, int row0, int buf_rows, skv_stream_t stream);
+
 /* out[r][i] = silu(x[r][i]) * x[r][inter+i]  (vllm._custom_ops.silu_and_mul, llama.py:421) */
 SKV_EXPORT int skv_silu_and_mul(const void* x, void* out, int rows, int inter, skv_stream_t stream);
 

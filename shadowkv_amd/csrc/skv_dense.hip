@@ -138,6 +138,24 @@ __global__ __launch_bounds__(256) void skv_silu_and_mul_kernel(const bf16_t* __r
     }
 }
 
+// update_kv_cache for a handful of new tokens (/root/reference/models/kv_cache.py:1227-1271): rows [row0, row0 + incoming)
+// of both cache buffers <- the new K / V rows; rows past the buffer are dropped like the reference's zero-length slice.
+// One 256-thread block per (batch, head, new token): threads 0..15 x 2 buffers move 16 B each.
+__global__ __launch_bounds__(64) void skv_append_kv_kernel(const u32x4* __restrict__ k_new, const u32x4* __restrict__ v_new,
+                                                          u32x4* __restrict__ k_buf, u32x4* __restrict__ v_buf,
+                                                          long long k_stride_b, long long k_stride_h, long long k_stride_s,
+                                                          long long v_stride_b, long long v_stride_h, long long v_stride_s,
+                                                          long long buf_stride_b, long long buf_stride_h, int row0, int rows) {
+    const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int row = row0 + t;
+    if (row < 0 || row >= rows || tid >= 32) return;
+    const int unit = tid & 15;
+    const u32x4* src = tid < 16 ? k_new + (b * k_stride_b + h * k_stride_h + t * k_stride_s) / 8 + unit
+                                : v_new + (b * v_stride_b + h * v_stride_h + t * v_stride_s) / 8 + unit;
+    u32x4* dst = (tid < 16 ? k_buf : v_buf) + (b * buf_stride_b + h * buf_stride_h) / 8 + (long long)row * 16 + unit;
+    *dst = *src;
+}
+
 static int finish_launch() { return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH; }
 
 extern "C" {
@@ -169,6 +187,21 @@ int skv_add_rmsnorm(const void* x, const void* residual, const void* weight, voi
     if (hidden % 8 || hidden > 8192) return SKV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(skv_add_rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (const bf16_t*)residual, (const bf16_t*)weight, (bf16_t*)h_out, (bf16_t*)y, hidden, eps);
+    return finish_launch();
+}
+
+int skv_update_kv_cache(const void* k_new, const void* v_new, void* k_buf, void* v_buf, int batch_size, int heads,
+                        int incoming, int head_dim, long long k_stride_b, long long k_stride_h, long long k_stride_s,
+                        long long v_stride_b, long long v_stride_h, long long v_stride_s, long long buf_stride_b,
+                        long long buf_stride_h, int row0, int buf_rows, skv_stream_t stream) {
+    if (!k_new || !v_new || !k_buf || !v_buf || batch_size < 1 || heads < 1 || incoming < 1) return SKV_ERR_ARG;
+    if (head_dim != 128) return SKV_ERR_UNSUPPORTED;
+    if (((k_stride_b | k_stride_h | k_stride_s | v_stride_b | v_stride_h | v_stride_s | buf_stride_b | buf_stride_h) % 8) ||
+        (((size_t)k_new | (size_t)v_new | (size_t)k_buf | (size_t)v_buf) & 15))
+        return SKV_ERR_ARG;
+    hipLaunchKernelGGL(skv_append_kv_kernel, dim3(incoming, heads, batch_size), dim3(64), 0, (hipStream_t)stream,
+                       (const u32x4*)k_new, (const u32x4*)v_new, (u32x4*)k_buf, (u32x4*)v_buf, k_stride_b, k_stride_h,
+                       k_stride_s, v_stride_b, v_stride_h, v_stride_s, buf_stride_b, buf_stride_h, row0, buf_rows);
     return finish_launch();
 }
 

@@ -621,8 +621,18 @@ class ShadowKVCache_CPU:
         incoming = new_k_cache.shape[-2]
         lo = self.sparse_end + self.gen_offset
         lv = self._layer(layer_idx)
-        lv.vbuf[:, :, lo:lo + incoming].copy_(new_v_cache, non_blocking=True)
-        lv.kbuf[:, :, lo:lo + incoming].copy_(new_k_cache, non_blocking=True)
+        k, v = new_k_cache, new_v_cache
+        if (k.is_cuda and k.dtype == torch.bfloat16 and k.shape[-1] == 128 and k.stride(-1) == 1 and v.stride(-1) == 1
+                and not ((k.stride(0) | k.stride(1) | k.stride(2) | v.stride(0) | v.stride(1) | v.stride(2)) % 8)
+                and not ((k.data_ptr() | v.data_ptr()) % 16)):
+            kb = lv.kbuf                                        # one native launch for both buffers
+            check(lib().skv_update_kv_cache(ptr(k), ptr(v), ptr(kb), ptr(lv.vbuf), k.shape[0], k.shape[1], incoming, 128,
+                                            k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+                                            kb.stride(0), kb.stride(1), lo, kb.shape[2], current_stream_handle()),
+                  "update_kv_cache")
+        else:
+            lv.vbuf[:, :, lo:lo + incoming].copy_(v, non_blocking=True)
+            lv.kbuf[:, :, lo:lo + incoming].copy_(k, non_blocking=True)
         if layer_idx == self.num_layers - 1:
             self.kv_offset += incoming
             self.gen_offset += incoming

@@ -136,12 +136,39 @@ class DecoderLM:
         return n * 2
 
     # --------------------------------------------------------------- per-layer pieces (llama.py:283-427)
+    def _decode_scratch(self, bs):
+        """Result buffers of the one-token-per-sequence path of the reference-shaped methods (pre_attention_compute,
+        apply_rotary_pos_emb, post_attention_compute), reused from layer to layer: every one of them is consumed on the
+        stream before the same method of the next layer overwrites it (torch.empty per call was ~20 us of host time per
+        layer on the eager call-order path).  Two sets alternate so that a layer's output never aliases its input."""
+        sc = getattr(self, "_scratch", None)
+        if sc is None or sc["bs"] != bs:
+            dev, dt, h = self.device, self.dtype, self.hidden_size
+            layer = self.layers[0]
+            n_qkv = layer.q_size + 2 * layer.kv_size
+
+            def one():
+                return dict(qkv=torch.empty(bs, 1, n_qkv, device=dev, dtype=dt),
+                            q=torch.empty(bs, self.num_heads, 1, self.head_dim, device=dev, dtype=dt),
+                            k=torch.empty(bs, self.num_key_value_heads, 1, self.head_dim, device=dev, dtype=dt),
+                            v=torch.empty(bs, self.num_key_value_heads, 1, self.head_dim, device=dev, dtype=dt),
+                            attn=torch.empty(bs, 1, self.num_heads, self.head_dim, device=dev, dtype=dt),
+                            o=torch.empty(bs, 1, h, device=dev, dtype=dt), h=torch.empty(bs, 1, h, device=dev, dtype=dt),
+                            act=torch.empty(bs, 1, layer.gate_up_proj.shape[0] // 2, device=dev, dtype=dt),
+                            down=torch.empty(bs, 1, h, device=dev, dtype=dt), out=torch.empty(bs, 1, h, device=dev, dtype=dt))
+            sc = dict(bs=bs, sets=[one(), one()], i=0, row0=torch.zeros(1, dtype=torch.long, device=dev))
+            self._scratch = sc
+        return sc
+
     def pre_attention_compute(self, hidden_states, layer):
         """RMSNorm -> fused QKV projection -> split (llama.py:283-303).  One decode token per sequence takes the native
         kernels (norm in the GEMV's prologue at bs 1, the rows GEMM for 2..32 sequences); prefill-sized inputs F.linear."""
         if hidden_states.shape[1] == 1 and hidden_states.is_cuda:
+            sc = self._decode_scratch(hidden_states.shape[0])
+            sc["i"] ^= 1                                        # (a new layer: the other buffer set)
             _, qkv = tensor_op.norm_linear_decode(hidden_states, None, layer.input_layernorm_weight,
-                                                  layer.input_layernorm_variance_epsilon, layer.wqkv, layer.bqkv)
+                                                  layer.input_layernorm_variance_epsilon, layer.wqkv, layer.bqkv,
+                                                  out=sc["sets"][sc["i"]]["qkv"])
         else:
             hs = tensor_op.layer_norm(hidden_states, layer.input_layernorm_variance_epsilon, layer.input_layernorm_weight)
             qkv = F.linear(hs, layer.wqkv, layer.bqkv)
@@ -158,12 +185,11 @@ class DecoderLM:
             # one decode token: q and k are the split views of the fused projection's output (pre_attention_compute) - ONE
             # native launch rotates both (the kernel of the fused step, its cache-push half pointed at a one-row scratch)
             qkv = q.as_strided((bs, 1, n_fused), (n_fused, n_fused, 1))
-            kr = torch.empty(bs, self.num_key_value_heads, 1, self.head_dim, dtype=q.dtype, device=q.device)
-            if getattr(self, "_row0", None) is None:
-                self._row0 = torch.zeros(1, dtype=torch.long, device=q.device)
-            qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, self._row0, kr, torch.empty_like(kr),
-                                           self.num_heads, self.num_key_value_heads)
-            return qr, kr
+            sc = self._decode_scratch(bs)
+            cur = sc["sets"][sc["i"]]
+            qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, sc["row0"], cur["k"], cur["v"],
+                                           self.num_heads, self.num_key_value_heads, q_out=cur["q"])
+            return qr, cur["k"]
         q = q.view(bs, s, self.num_heads, self.head_dim).transpose(1, 2)
         k = k.view(bs, s, self.num_key_value_heads, self.head_dim).transpose(1, 2)
         if self.cfg.rope_style == "neox":
@@ -184,11 +210,16 @@ class DecoderLM:
     def post_attention_compute(self, attn_output, residual, layer):
         """o-projection + residual -> RMSNorm -> gate/up -> SiLU*mul -> down + residual (llama.py:405-427)."""
         if attn_output.shape[1] == 1 and attn_output.is_cuda:       # one decode token per sequence: native kernels
-            o = tensor_op.linear_decode(attn_output, layer.wo)
+            sc = self._decode_scratch(attn_output.shape[0])
+            cur = sc["sets"][sc["i"]]
+            o = tensor_op.linear_decode(attn_output, layer.wo, out=cur["o"])
             residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
                                                          layer.post_attention_layernorm_variance_epsilon,
-                                                         layer.gate_up_proj, fuse_silu_mul=True)
-            return residual + tensor_op.linear_decode(act, layer.down_proj)
+                                                         layer.gate_up_proj, fuse_silu_mul=True, out=cur["act"], h_out=cur["h"])
+            if residual.shape[0] == 1:      # one sequence: the residual rides in the GEMV's bias slot (bf16(W.act) + residual,
+                #                             rounded like the separate add: same bits, one launch less)
+                return tensor_op.linear_decode(act, layer.down_proj, bias=residual, out=cur["out"])
+            return torch.add(residual, tensor_op.linear_decode(act, layer.down_proj, out=cur["down"]), out=cur["out"])
         hs = residual + F.linear(attn_output, layer.wo)
         residual = hs
         hs = tensor_op.layer_norm(hs, layer.post_attention_layernorm_variance_epsilon,
@@ -211,15 +242,23 @@ class DecoderLM:
         cache = self.kv_cache
         cache.update_kv_cache(k, v, layer_idx)
         chunk_ids = cache.get_retrieval_position_ids(layer_idx=layer_idx, query_states=q)
+        # base.py:326-338: V fetch under copy_stream || K rebuild on the current stream, joined before the attention.
+        # (wait_stream makes a new event per call; two events of the model are recorded again and again instead)
         curr = torch.cuda.current_stream()
         side = cache.copy_stream
+        if getattr(self, "_fork_ev", None) is None:
+            self._fork_ev, self._join_ev = torch.cuda.Event(), torch.cuda.Event()
+        self._fork_ev.record(curr)
         with torch.cuda.stream(side):
-            side.wait_stream(curr)
+            side.wait_event(self._fork_ev)
             v_view = cache.get_value_cache(layer_idx, chunk_ids)
+            self._join_ev.record(side)
         k_view = cache.get_key_cache(layer_idx=layer_idx, position_ids=chunk_ids, rope_func=None,
                                      cos_sin_cache=self.cos_sin_cache)
-        curr.wait_stream(side)
-        attn = tensor_op.sparse_attention_decode(q, k_view, v_view)
+        curr.wait_event(self._join_ev)
+        sc = getattr(self, "_scratch", None)
+        attn = tensor_op.sparse_attention_decode(q, k_view, v_view, out=None if sc is None or q_len != 1 or sc["bs"] != bsz
+                                                 else sc["sets"][sc["i"]]["attn"])
         return self.post_attention_compute(attn.reshape(bsz, q_len, self.hidden_size), residual, layer)
 
     # --------------------------------------------------------------- fused decode step (MI355X launch sequence)
@@ -383,15 +422,18 @@ class QueryWalk:
         self.q = torch.randn(model.num_layers, model.batch_size, model.num_heads, 1, D, device=dev, generator=self.g)
         self.q = self.q / self.q.norm(dim=-1, keepdim=True) * self.norm
         self.qb = self.q.to(model.dtype)
+        self.qb_layers = self.qb.unbind(0)
+        self._zero = torch.zeros((), device=dev, dtype=model.dtype)
 
     def advance(self):
         n = torch.randn(self.q.shape, device=self.q.device, generator=self.g)
         self.q = self.q + self.step * self.norm / math.sqrt(self.q.shape[-1]) * n
         self.q = self.q / self.q.norm(dim=-1, keepdim=True) * self.norm
         self.qb = self.q.to(self.qb.dtype)
+        self.qb_layers = self.qb.unbind(0)
 
     def __call__(self, layer_idx, q_model):
-        return torch.addcmul(self.qb[layer_idx], q_model, torch.zeros((), device=q_model.device, dtype=q_model.dtype))
+        return torch.addcmul(self.qb_layers[layer_idx], q_model, self._zero)
 
 
 class GraphDecoder:

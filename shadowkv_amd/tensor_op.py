@@ -38,7 +38,7 @@ def silu_and_mul(out, x):
 MAX_GEMV_ROWS = 32   # token rows served by the native kernels (1: GEMV, 2..32: small-M MFMA kernel); more -> F.linear
 
 
-def linear_decode(x, w, bias=None, fuse_silu_mul=False):
+def linear_decode(x, w, bias=None, fuse_silu_mul=False, out=None):
     """F.linear for decode-time activations (x [..., K] with a handful of token rows): one token -> the native GEMV,
     2..MAX_GEMV_ROWS tokens -> the native small-M MFMA kernel (weights stream once); falls back to F.linear for more
     rows or shapes the kernels are not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
@@ -49,7 +49,7 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False):
         return silu_and_mul_fused(out) if fuse_silu_mul else out
     N = w.shape[0]
     No = (N // 2) if fuse_silu_mul else N
-    y = torch.empty(x.shape[:-1] + (No,), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty(x.shape[:-1] + (No,), dtype=x.dtype, device=x.device)
     if rows == 1:
         check(lib().skv_gemv_bf16(ptr(w), ptr(x), ptr(bias), ptr(y), N, K, 1 if fuse_silu_mul else 0,
                                   current_stream_handle()), "gemv")
@@ -59,16 +59,17 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False):
     return y
 
 
-def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False):
+def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False, out=None, h_out=None):
     """(h, y): h = x + residual (residual None -> h = x), y = linear(RMSNorm(h) * norm_w) for one token, one
-    native launch when the hidden size is 4096; otherwise add_rmsnorm + linear_decode."""
+    native launch when the hidden size is 4096; otherwise add_rmsnorm + linear_decode.  out / h_out: caller-owned
+    result buffers (the eager decode paths reuse theirs instead of allocating per call)."""
     K = x.shape[-1]
     if x.numel() != K or K != 4096 or not x.is_contiguous() or not w.is_contiguous():
         h, hs = add_rmsnorm(x, residual, norm_w, eps)
-        return h, linear_decode(hs, w, bias, fuse_silu_mul)
+        return h, linear_decode(hs, w, bias, fuse_silu_mul, out=out)
     N = w.shape[0]
-    y = torch.empty(x.shape[:-1] + ((N // 2) if fuse_silu_mul else N,), dtype=x.dtype, device=x.device)
-    h = torch.empty_like(x) if residual is not None else x
+    y = out if out is not None else torch.empty(x.shape[:-1] + ((N // 2) if fuse_silu_mul else N,), dtype=x.dtype, device=x.device)
+    h = (h_out if h_out is not None else torch.empty_like(x)) if residual is not None else x
     check(lib().skv_norm_gemv_bf16(ptr(w), ptr(x), ptr(residual), ptr(norm_w), float(eps),
                                    ptr(h) if residual is not None else 0, ptr(bias), ptr(y), N, K,
                                    1 if fuse_silu_mul else 0, current_stream_handle()), "norm_gemv")
@@ -96,13 +97,13 @@ def silu_and_mul_fused(x):
     return out
 
 
-def qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_heads, q_override=None):
+def qkv_rope_update(qkv, cos_sin, pos, row_idx, k_cache, v_cache, q_heads, kv_heads, q_override=None, q_out=None):
     """qkv [bs, 1, (Hq+2Hkv)*D] -> q [bs, Hq, 1, D] rotated at pos [bs] (int64, device); k (rotated) and v are
     written into row row_idx[0] (int64, device) of k_cache / v_cache [bs, Hkv, rows, D].  One native launch."""
     bs = qkv.shape[0]
     D = k_cache.shape[-1]
     width = cos_sin.shape[-1]
-    q = torch.empty(bs, q_heads, 1, D, dtype=qkv.dtype, device=qkv.device)
+    q = q_out if q_out is not None else torch.empty(bs, q_heads, 1, D, dtype=qkv.dtype, device=qkv.device)
     check(lib().skv_qkv_rope_update(ptr(qkv), ptr(cos_sin), ptr(pos), ptr(row_idx), ptr(q_override), ptr(q),
                                     ptr(k_cache), ptr(v_cache), bs, q_heads, kv_heads, D, cos_sin.stride(0),
                                     cos_sin.shape[0], k_cache.stride(0), k_cache.stride(1), k_cache.shape[2],

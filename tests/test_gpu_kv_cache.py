@@ -360,6 +360,9 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     (oracle.apply_rotary_pos_emb_push_cache_opt_glm if glm else oracle.apply_rotary_pos_emb_push_cache_opt)(
         pre, csc, ids32, kor, zero, *ints)
     kd = (kor.float() - kbuf.float()).abs()[0][:, cache.sparse_start:cache.sparse_end]
+    record_parity(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}]",
+                  ulp_diff_bf16(kor[0][:, cache.sparse_start:cache.sparse_end], kbuf[0][:, cache.sparse_start:cache.sparse_end]),
+                  "post-RoPE")     # (hit rows were placed by the prefill's torch einsum, miss rows by the rebuild kernel)
     bound = rope_pair_bound(pre[0], glm)
     assert bool((kd <= bound).all()), f"K rows exceed the bound by {float((kd - bound).max())}"
     # attention: F32 oracle over the device's own K / V bytes
