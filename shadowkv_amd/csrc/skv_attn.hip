@@ -18,6 +18,10 @@
 #include "../../include/shadowkv_hip.h"
 #include "skv_attn_body.h"
 
+#ifndef SKV_ATTN_PV_MAX_PAIRS
+#define SKV_ATTN_PV_MAX_PAIRS 64   // (batch, kv head) pairs up to which the all-MFMA split pass is used (0: never)
+#endif
+
 template <int G, bool LISTED>
 __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     const bf16_t* __restrict__ q,   // [bs][Hq][128]
@@ -38,6 +42,17 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
         skv_attn_partial_body<G, LISTED>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
                                          LISTED ? slots + (size_t)blockIdx.y * n_slots : nullptr, n_slots, sparse_start,
                                          resident_rows);
+}
+
+// Both products on the matrix pipe (skv_attn_partial_body_mfma_pv): latency-bound shapes - one sequence, small batches.
+template <int G>
+__global__ __launch_bounds__(256, 3) void skv_attn_partial_pv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                     const bf16_t* __restrict__ v, float* __restrict__ ws,
+                                                                     const int* __restrict__ kv_len_dev, int kv_len_host,
+                                                                     int kv_rows, long long kv_stride_h, int splits, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int kv_len = min(kv_len_dev ? *kv_len_dev : kv_len_host, kv_rows);
+    skv_attn_partial_body_mfma_pv<G>(q, k, v, ws, kv_len, kv_stride_h, splits, blockIdx.x, blockIdx.y, scale, s_dyn);
 }
 
 __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
@@ -139,6 +154,23 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         return SKV_ERR_ARG;
     const int G = Hq / Hkv;
     dim3 grid(splits, bs * Hkv), block(256);
+    // Which body (tools/attn_mfma_probe.hip, profiles/r03_attn_pv_probe.txt): up to SKV_ATTN_PV_MAX_PAIRS (batch, head) pairs
+    // the pass is latency / issue bound and both products go to the matrix pipe (P in bf16, like flash-attn); beyond, it is
+    // HBM-bound: Q.K^T on the MFMA for G = 8, the VALU body for G <= 4.  A slot list (resident set larger than the
+    // selection) always takes the VALU body.
+    if (!slots && (G == 4 || G == 8) && bs * Hkv <= SKV_ATTN_PV_MAX_PAIRS) {
+        if (G == 4)
+            hipLaunchKernelGGL(skv_attn_partial_pv_kernel<4>, grid, block, SKV_ATTN_PV_LDS_BYTES(4), st, (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows, kv_stride_h,
+                               splits, scale);
+        else
+            hipLaunchKernelGGL(skv_attn_partial_pv_kernel<8>, grid, block, SKV_ATTN_PV_LDS_BYTES(8), st, (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows, kv_stride_h,
+                               splits, scale);
+        hipLaunchKernelGGL(skv_attn_combine_kernel, dim3(bs * Hq), dim3(128), (size_t)splits * AT_REC * sizeof(float), st,
+                           (const float*)ws, (bf16_t*)out, splits);
+        return SKV_OK;
+    }
     const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float) + (slots ? (size_t)n_slots * sizeof(int) : 0) +
                         (G == 8 && !slots ? SKV_ATTN_MFMA_LDS_FLOATS * sizeof(float) : 0);
 #define SKV_AT_L(GG, LL)                                                                                        \

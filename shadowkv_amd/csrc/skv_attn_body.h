@@ -261,3 +261,152 @@ __device__ __forceinline__ void skv_attn_partial_body_mfma(const bf16_t* __restr
         if (d == 0) { dst[AT_D] = M; dst[AT_D + 1] = L; }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: BOTH products on the matrix pipe (tools/attn_mfma_probe.hip, profiles/r03_attn_pv_probe.txt: 19 % faster than
+// the VALU pass at G = 4 and 30 % at G = 8 where the pass is latency / issue bound - one sequence or a small batch; no gain
+// at 192 (batch, head) pairs, where it is HBM-bound).  A wave takes 32 keys per step:
+//   scores   two 16-key tiles C_t[key 16 t + 4 c + i][g = l & 15] (c = l >> 4, i = register) = K Q^T as above;
+//   softmax  per column lane g: running max over the lane's 8 scores and the 4 lane groups (two xor shuffles), p = exp(s - m);
+//   P.V      out[g][d] = sum_key p[g][key] V[key][d] as v_mfma_f32_16x16x32_bf16 with A = P^T STRAIGHT from the score
+//            registers: X = K Q^T has the key on its rows, so X^T V sums over X's row index and needs no lane movement
+//            (A element j of lane (g, c) = p of key 16 (j >> 2) + 4 c + (j & 3)); B = V under the SAME key permutation,
+//            read k-major from a wave-private LDS image of the 32 V rows with ds_read_b64_tr_b16 (two 4-row x 16-column
+//            blocks per fragment); 8 column blocks of 16 dims -> 8 MFMAs + 16 transposed reads per 32 keys; accumulators
+//            O[g = 4 c + i][d = 16 nb + (l & 15)], rescaled per step with exp(m_old - m_new) of ROW g (four shuffles).
+// P is rounded to bf16 for the MFMA (as flash-attn, the reference's attention, does): |out - out_f32P| <= 2^-9 times the
+// attention-weighted mean of |V| (tests add exactly that term).  LDS: [4 waves][G][130] partials + 4 x 32 x 256 B images.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SKV_ATTN_PV_LDS_BYTES(G) ((size_t)4 * (G) * (AT_D + 2) * sizeof(float) + 4 * 32 * 256)
+__device__ __forceinline__ uint32_t skv_lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ u32x2 skv_ds_read_tr16(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+// byte offset of 16-byte chunk ch of row `row` in a [rows][256 B] image (MI355X guide T10, image (b): conflict-free for the
+// row-wise 16-B stores and for the transposed reads)
+__device__ __forceinline__ uint32_t skv_v_off(int row, int ch) { return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int G>
+__device__ __forceinline__ void skv_attn_partial_body_mfma_pv(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                              const bf16_t* __restrict__ v, float* __restrict__ ws, int kv_len,
+                                                              long long stride_h, int splits, int split, int bh, float scale,
+                                                              float* s_dyn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, c4 = lane >> 4;
+    const int per = (kv_len + splits - 1) / splits, k0 = split * per, k1 = min(k0 + per, kv_len);
+    float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_dyn);           // [4 waves][G][130]
+    unsigned char* s_v = reinterpret_cast<unsigned char*>(s_dyn + 4 * G * (AT_D + 2)) + wave * 32 * 256;   // [32 rows][256 B]
+    at_bf16x8 bq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (sub < G) w = *reinterpret_cast<const u32x4*>(q + ((size_t)bh * G + sub) * AT_D + 32 * ks + 8 * c4);
+        bq[ks] = __builtin_bit_cast(at_bf16x8, w);
+    }
+    float m = -INFINITY, lsum = 0.f;                   // of head g = sub (lanes sub >= G: padding columns)
+    at_f32x4 o[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) o[nb] = (at_f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* kb = k + (size_t)bh * stride_h;
+    const bf16_t* vb = v + (size_t)bh * stride_h;
+    const uint32_t sv_base = skv_lds_addr_of(s_v);
+    for (int key0 = k0 + wave * 32; key0 < k1; key0 += 128) {      // 4 waves x 32 keys per step (wave-uniform trip count)
+        u32x4 ak[2][4], vr[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kr = min(key0 + 16 * t + sub, k1 - 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ak[t][ks] = *reinterpret_cast<const u32x4*>(kb + (size_t)kr * AT_D + 32 * ks + 8 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)                                  // V rows c4 + 4 i, chunk sub (1 KiB per wave-instruction)
+            vr[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)min(key0 + c4 + 4 * i, k1 - 1) * AT_D + 8 * sub);
+        at_f32x4 sc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            sc[t] = (at_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, ak[t][ks]), bq[ks], sc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(s_v + skv_v_off(c4 + 4 * i, sub)) = vr[i];
+        // online softmax of head g = sub over the step's 32 keys
+        float s8[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = key0 + 16 * t + 4 * c4 + i;
+                s8[4 * t + i] = key < k1 ? sc[t][i] * scale : -INFINITY;
+                mx = fmaxf(mx, s8[4 * t + i]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);                                // finite: key0 < k1 is alive
+        const float corr = __expf(m - mn);                            // first step: exp(-inf) = 0
+        m = mn;
+        uint32_t pa[4];
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p0 = __expf(s8[2 * j] - mn), p1 = __expf(s8[2 * j + 1] - mn);
+            ps += p0 + p1;
+            pa[j] = pack_bf2(p0, p1);
+        }
+        lsum = lsum * corr + ps;
+        // rescale the accumulators: row 4 c + i needs the factor of head g = 4 c + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float cr = __shfl(corr, 4 * c4 + i, 64);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) o[nb][i] *= cr;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the wave's V image is written (same-wave LDS order)
+        const at_bf16x8 afrag = __builtin_bit_cast(at_bf16x8, (u32x4){pa[0], pa[1], pa[2], pa[3]});
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            // lane 4 q + p of the 16-lane group supplies row r0 + q, columns 4 p .. 4 p + 3 of the block (chunk 2 nb + (p >> 1));
+            // every lane issues the read (the transposing read needs EXEC all ones: the loop's trip count is wave-uniform)
+            const int qrow = sub >> 2, pp = sub & 3;
+            const u32x2 b0 = skv_ds_read_tr16(sv_base + skv_v_off(4 * c4 + qrow, 2 * nb + (pp >> 1)) + 8 * (pp & 1));
+            const u32x2 b1 = skv_ds_read_tr16(sv_base + skv_v_off(16 + 4 * c4 + qrow, 2 * nb + (pp >> 1)) + 8 * (pp & 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const at_bf16x8 bfrag = __builtin_bit_cast(at_bf16x8, (u32x4){b0[0], b0[1], b1[0], b1[1]});
+            o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, o[nb], 0, 0, 0);
+        }
+    }
+    // l of head g: the four lane groups hold partial sums
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    // wave partial -> LDS: o[nb][i] = out[g = 4 c + i][d = 16 nb + sub]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = 4 * c4 + i;
+        if (g < G) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) s_part[wave][g][16 * nb + sub] = o[nb][i];
+        }
+    }
+    if (c4 == 0 && sub < G) { s_part[wave][sub][AT_D] = m; s_part[wave][sub][AT_D + 1] = lsum; }
+    __syncthreads();
+    for (int oo = tid; oo < G * AT_D; oo += 256) {
+        const int g = oo / AT_D, d = oo % AT_D;
+        float M = -INFINITY;
+        for (int r = 0; r < 4; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
+        float a = 0.f, L = 0.f;
+        for (int r = 0; r < 4; ++r) {                     // (a wave that had no key in range holds m = -inf, acc = l = 0)
+            const float mr = s_part[r][g][AT_D], w = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+            a = __builtin_fmaf(s_part[r][g][d], w, a);
+            L = __builtin_fmaf(s_part[r][g][AT_D + 1], w, L);
+        }
+        float* dst = ws + (((size_t)bh * G + g) * splits + split) * AT_REC;
+        dst[d] = a;
+        if (d == 0) { dst[AT_D] = M; dst[AT_D + 1] = L; }
+    }
+}

@@ -32,13 +32,28 @@ def _dt(t, dtype, name):
 def _d2d_staging(device, rows):
     """Staging rows (2 KiB each) for the hit chunks gather_copy_d2d_with_offsets moves; the reference's signature has
     no bounce buffer for the K side (one CTA per (batch, head) serialises it, copy.cuh:649-687).  Per (device, stream):
-    two streams may compact concurrently."""
+    two streams may compact concurrently.  Allocated at the first call (or by reserve_d2d_staging); never under stream
+    capture - a captured launch sequence must not allocate: reserve before capturing."""
     key = (device.type, device.index, current_stream_handle())
     s = _staging.get(key)
     if s is None or s.shape[0] < rows:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gather_copy_d2d_with_offsets needs a staging buffer of %d rows and the stream is being "
+                               "captured: call shadowkv.reserve_d2d_staging(device, rows) under this stream first" % rows)
         s = torch.empty(rows, 1024, dtype=torch.bfloat16, device=device)
         _staging[key] = s
     return s
+
+
+def reserve_d2d_staging(device, rows):
+    """Allocates the staging buffer of gather_copy_d2d_with_offsets for the current stream ahead of time (rows =
+    batch_size * heads * map_size)."""
+    return _d2d_staging(torch.device(device), rows)
+
+
+def release_d2d_staging():
+    """Drops every staging buffer (they are kept per (device, stream) until released)."""
+    _staging.clear()
 
 
 def gather_copy(values, v_cache_buffer, position_ids, batch_size, heads, cpu_v_length, gpu_v_length, map_size):

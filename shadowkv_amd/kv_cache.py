@@ -615,6 +615,17 @@ class ShadowKVCache_CPU:
         """Rows left for generated tokens behind the sparse region (buf_len - sparse_end; 96 at the 122K config)."""
         return self.k_cache_buffer.shape[-2] - self.sparse_end - self.gen_offset
 
+    def incoming_rows_writable(self, incoming):
+        """True when `incoming` new rows fit behind the sparse region (a caller that pushes them itself must not write past
+        the buffer; the reference drops such rows)."""
+        return self.sparse_end + self.gen_offset + incoming <= self.k_cache_buffer.shape[-2]
+
+    def note_rows_pushed(self, layer_idx, row, incoming):
+        """The host model's RoPE launch has already written the new token's rotated K and its V into rows [row, row +
+        incoming) of this layer's buffers (DecoderLM.apply_rotary_pos_emb); the update_kv_cache call that follows for the
+        same layer and rows does the bookkeeping only."""
+        self._pushed = (layer_idx, row, incoming)
+
     def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
         """Appends the new token's K / V after the sparse region (kv_cache.py:1227-1271); rows past
         the end of the buffer are dropped exactly as the reference's zero-length slice does."""
@@ -622,7 +633,10 @@ class ShadowKVCache_CPU:
         lo = self.sparse_end + self.gen_offset
         lv = self._layer(layer_idx)
         k, v = new_k_cache, new_v_cache
-        if (k.is_cuda and k.dtype == torch.bfloat16 and k.shape[-1] == 128 and k.stride(-1) == 1 and v.stride(-1) == 1
+        pushed, self._pushed = getattr(self, "_pushed", None), None
+        if pushed == (layer_idx, lo, incoming) and k.data_ptr() == lv.kbuf.data_ptr() + lo * self.head_dim * 2:
+            pass                                                # rows already in place (see note_rows_pushed)
+        elif (k.is_cuda and k.dtype == torch.bfloat16 and k.shape[-1] == 128 and k.stride(-1) == 1 and v.stride(-1) == 1
                 and not ((k.stride(0) | k.stride(1) | k.stride(2) | v.stride(0) | v.stride(1) | v.stride(2)) % 8)
                 and not ((k.data_ptr() | v.data_ptr()) % 16)):
             kb = lv.kbuf                                        # one native launch for both buffers

@@ -156,7 +156,8 @@ class DecoderLM:
                             o=torch.empty(bs, 1, h, device=dev, dtype=dt), h=torch.empty(bs, 1, h, device=dev, dtype=dt),
                             act=torch.empty(bs, 1, layer.gate_up_proj.shape[0] // 2, device=dev, dtype=dt),
                             down=torch.empty(bs, 1, h, device=dev, dtype=dt), out=torch.empty(bs, 1, h, device=dev, dtype=dt))
-            sc = dict(bs=bs, sets=[one(), one()], i=0, row0=torch.zeros(1, dtype=torch.long, device=dev))
+            sc = dict(bs=bs, sets=[one(), one()], i=0, row0=torch.zeros(1, dtype=torch.long, device=dev),
+                      row=torch.zeros(1, dtype=torch.long, device=dev), row_host=None)
             self._scratch = sc
         return sc
 
@@ -175,20 +176,42 @@ class DecoderLM:
         q, k, v = qkv.split([layer.q_size, layer.kv_size, layer.kv_size], dim=-1)
         return q, k, v.view(v.shape[0], -1, self.num_key_value_heads, self.head_dim).transpose(1, 2)
 
-    def apply_rotary_pos_emb(self, q, k, position_ids):
-        """q [bs, s, Hq*D], k [bs, s, Hkv*D] -> [bs, H, s, D] rotated at position_ids [bs, s]."""
+    def apply_rotary_pos_emb(self, q, k, position_ids, layer_idx=None):
+        """q [bs, s, Hq*D], k [bs, s, Hkv*D] -> [bs, H, s, D] rotated at position_ids [bs, s].
+        layer_idx (optional, one decode token, ShadowKV cache): the native launch that rotates q and k ALSO pushes the
+        rotated k and v into the layer's cache row - what update_kv_cache is about to do (kv_cache.py:1227-1271) - and the
+        cache is told, so that update_kv_cache finds the rows in place and only does its bookkeeping; a synthetic-query
+        hook (bench: QueryWalk) rides in the kernel's q-override slot instead of a separate launch."""
         bs, s = q.shape[0], q.shape[1]
         n_fused = (self.num_heads + 2 * self.num_key_value_heads) * self.head_dim
+        self._hook_applied = False
         if (s == 1 and q.is_cuda and q.stride(-1) == 1 and q.stride(0) == n_fused and k.stride(0) == n_fused
                 and q.untyped_storage().data_ptr() == k.untyped_storage().data_ptr()
                 and k.storage_offset() - q.storage_offset() == self.num_heads * self.head_dim):
             # one decode token: q and k are the split views of the fused projection's output (pre_attention_compute) - ONE
-            # native launch rotates both (the kernel of the fused step, its cache-push half pointed at a one-row scratch)
+            # native launch rotates both (the kernel of the fused step)
             qkv = q.as_strided((bs, 1, n_fused), (n_fused, n_fused, 1))
             sc = self._decode_scratch(bs)
             cur = sc["sets"][sc["i"]]
+            hook = self.query_hook
+            q_over = None
+            if layer_idx is not None and hook is not None and hasattr(hook, "qb_layers"):
+                q_over = hook.qb_layers[layer_idx]
+                self._hook_applied = True
+            c = self.kv_cache
+            if layer_idx is not None and self.attn_mode != "full" and c.incoming_rows_writable(1):
+                row = c.sparse_end + c.gen_offset
+                if sc.get("row_host") != row:
+                    sc["row"].fill_(row)
+                    sc["row_host"] = row
+                lv = c._layer(layer_idx)
+                kbuf, vbuf = lv.kbuf, lv.vbuf
+                qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, sc["row"], kbuf, vbuf, self.num_heads,
+                                               self.num_key_value_heads, q_override=q_over, q_out=cur["q"])
+                c.note_rows_pushed(layer_idx, row, 1)
+                return qr, kbuf[:, :, row:row + 1]
             qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, sc["row0"], cur["k"], cur["v"],
-                                           self.num_heads, self.num_key_value_heads, q_out=cur["q"])
+                                           self.num_heads, self.num_key_value_heads, q_override=q_over, q_out=cur["q"])
             return qr, cur["k"]
         q = q.view(bs, s, self.num_heads, self.head_dim).transpose(1, 2)
         k = k.view(bs, s, self.num_key_value_heads, self.head_dim).transpose(1, 2)
@@ -236,8 +259,8 @@ class DecoderLM:
         residual = hidden_states
         bsz, q_len, _ = hidden_states.shape
         q, k, v = self.pre_attention_compute(hidden_states, layer)
-        q, k = self.apply_rotary_pos_emb(q, k, position_ids)
-        if self.query_hook is not None:
+        q, k = self.apply_rotary_pos_emb(q, k, position_ids, layer_idx=layer_idx)
+        if self.query_hook is not None and not self._hook_applied:
             q = self.query_hook(layer_idx, q)
         cache = self.kv_cache
         cache.update_kv_cache(k, v, layer_idx)

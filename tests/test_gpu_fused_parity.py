@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from util import ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step, check_topk_against_reference, record_parity, REBUILD_FLIP_BOUND
+from util import attention_tolerance, ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step, check_topk_against_reference, record_parity, REBUILD_FLIP_BOUND
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -384,6 +384,7 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
     v = torch.randn(bs, Hkv, rows, 128, generator=g).bfloat16()
     scale = 1.0 / math.sqrt(128)
     o0, o0f = oracle.sparse_attention(q, k, v, kv_len, scale)
+    _, o0abs = oracle.sparse_attention(q, k, v.abs(), kv_len, scale)     # weighted mean of |V|: the bf16-P term of the bound
     L = _lib()
     ws = torch.empty(L.lib().skv_attn_workspace_bytes(bs, Hq, splits), dtype=torch.uint8, device=DEV)
     out = torch.zeros(bs, Hq, 128, dtype=torch.bfloat16, device=DEV)
@@ -396,9 +397,10 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
         L.check(rc, "skv_sparse_attention")
         torch.cuda.synchronize()
         o1 = out.cpu().float()
-        # tolerance: fp16-level 1e-3 relative (north_star) + half a bf16 ulp of the output rounding
-        tol = 1e-3 * o0f.abs() + 2.0 ** -8 * o0f.abs() + 1e-5
-        assert bool(((o1 - o0f).abs() <= tol).all()), f"max abs err {float((o1 - o0f).abs().max())}"
+        # tolerance: fp16-level 1e-3 relative (north_star) + half a bf16 ulp of the output rounding (+ the bf16 softmax
+        # weights of the all-MFMA pass, which small (batch, head) counts with G = 4 / 8 take)
+        tol = attention_tolerance(o0f, o0abs)
+        assert bool(((o1 - o0f).abs() <= tol).all()), f"max excess {float(((o1 - o0f).abs() - tol).max())}"
     # kv_len past the rows a head owns: refused from the host, clamped from the device (never reads the next head)
     a = (qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), ws.data_ptr())
     assert L.lib().skv_sparse_attention(*a, 0, rows + 1, rows, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream()) == -1
@@ -407,4 +409,5 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
                                          _stream()), "skv_sparse_attention")
     torch.cuda.synchronize()
     _, full = oracle.sparse_attention(q, k, v, rows, scale)
-    assert bool(((out.cpu().float() - full).abs() <= 1e-3 * full.abs() + 2.0 ** -8 * full.abs() + 1e-5).all())
+    _, fullabs = oracle.sparse_attention(q, k, v.abs(), rows, scale)
+    assert bool(((out.cpu().float() - full).abs() <= attention_tolerance(full, fullabs)).all())

@@ -41,6 +41,18 @@ def open_parity_record():
     return open(os.path.join(root, "gpurun_out", "rebuild_parity.txt"), "a")
 
 
+def attention_tolerance(ref32, absv32=None):
+    """Element-wise bound on |device - oracle f32| for the decode attention: 1e-3 |ref| (north star: fp16-level relative
+    error) + half a bf16 ulp of the output rounding + 1e-5.  absv32 (the oracle's attention over |V| with the same weights):
+    the pass that runs P.V on the matrix pipe rounds the softmax weights to bf16 first, exactly as the reference's
+    flash-attn does - each weight moves by at most 2^-9 relative, the output by at most 2^-9 x the attention-weighted mean
+    of |V|."""
+    tol = 1e-3 * ref32.abs() + 2.0 ** -8 * ref32.abs() + 1e-5
+    if absv32 is not None:
+        tol = tol + 2.0 ** -9 * absv32
+    return tol
+
+
 def record_parity(test, d, where="K rebuild"):
     """Appends the measured disagreement of a tolerance-compared result (d = ulp distances, any shape) to
     gpurun_out/rebuild_parity.txt: fraction of values that differ, maximum distance in bf16 ulps.  The bounds the tests

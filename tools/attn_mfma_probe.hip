@@ -342,5 +342,9 @@ int main() {
     // the standalone pass of a batch, where attention is NOT hidden behind PCIe: bs 24 x 8 KV heads (Llama), bs 8 x 4 (GLM)
     run<4>(192, 2497, 2, 4);
     run<8>(32, 2497, 8, 8);
+    // Llama batches 2 / 4 / 8 (tensor_op.sparse_attention_decode picks 256 / (bs * 8) splits)
+    run<4>(16, 2497, 16, 16);
+    run<4>(32, 2497, 8, 8);
+    run<4>(64, 2497, 4, 8);
     return 0;
 }
