@@ -19,7 +19,7 @@
 #include "skv_attn_body.h"
 
 #ifndef SKV_ATTN_PV_MAX_PAIRS
-#define SKV_ATTN_PV_MAX_PAIRS 64   // (batch, kv head) pairs up to which the all-MFMA split pass is used (0: never)
+#define SKV_ATTN_PV_MAX_PAIRS 64   // G = 4: (batch, kv head) pairs up to which the all-MFMA split pass is used (0: never)
 #endif
 
 template <int G, bool LISTED>
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void skv_attn_partial_kernel(
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     // never past the rows a head owns (the reference's view slice [:sparse_end + gen] clamps the same way)
     const int kv_len = min(kv_len_dev ? *kv_len_dev : kv_len_host, kv_rows);
-    if constexpr (G == 8 && !LISTED)      // Q.K^T on v_mfma_f32_16x16x32_bf16 (10-11 % faster at G = 8, a tie at G = 4)
+    // Q.K^T on v_mfma_f32_16x16x32_bf16: G = 8 (unless the launcher took the all-MFMA pass), and G = 4 where the launcher
+    // routes large batches here (it leaves room for the score tiles in the LDS request)
+    if constexpr ((G == 8 || G == 4) && !LISTED)
         skv_attn_partial_body_mfma<G>(q, k, v, ws, kv_len, kv_stride_h, splits, blockIdx.x, blockIdx.y, scale, s_dyn);
     else
         skv_attn_partial_body<G, LISTED>(q, k, v, ws, kv_len, kv_stride_h, splits, splits, blockIdx.x, blockIdx.y, scale, s_dyn,
@@ -154,11 +156,14 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         return SKV_ERR_ARG;
     const int G = Hq / Hkv;
     dim3 grid(splits, bs * Hkv), block(256);
-    // Which body (tools/attn_mfma_probe.hip, profiles/r03_attn_pv_probe.txt): up to SKV_ATTN_PV_MAX_PAIRS (batch, head) pairs
-    // the pass is latency / issue bound and both products go to the matrix pipe (P in bf16, like flash-attn); beyond, it is
-    // HBM-bound: Q.K^T on the MFMA for G = 8, the VALU body for G <= 4.  A slot list (resident set larger than the
-    // selection) always takes the VALU body.
-    if (!slots && (G == 4 || G == 8) && bs * Hkv <= SKV_ATTN_PV_MAX_PAIRS) {
+    // Which body (tools/attn_mfma_probe.hip, profiles/r03_attn_pv_probe.txt; VALU / Q.K^T on MFMA / both on MFMA, us):
+    //   G = 4:   8 pairs 6.96 / 6.89 / 5.58    16 pairs 8.94 / 8.88 / 8.13    32 pairs 12.5 / 13.0 / 12.3
+    //           64 pairs 20.4 / 21.8 / 19.8   192 pairs 53.2 / 48.6 / 49.7   (pairs = batch x KV heads)
+    //   G = 8:   4 pairs 7.36 / 6.59 / 5.12    32 pairs 18.1 / 16.7 / 12.8
+    // -> both products on the matrix pipe (P in bf16, like flash-attn) for G = 8 always and for G = 4 up to
+    // SKV_ATTN_PV_MAX_PAIRS pairs; larger G = 4 batches (HBM-bound) take Q.K^T on the MFMA, P.V on the VALU.  A slot list
+    // (resident set larger than the selection) always takes the VALU body.
+    if (!slots && ((G == 4 && bs * Hkv <= SKV_ATTN_PV_MAX_PAIRS) || G == 8)) {
         if (G == 4)
             hipLaunchKernelGGL(skv_attn_partial_pv_kernel<4>, grid, block, SKV_ATTN_PV_LDS_BYTES(4), st, (const bf16_t*)q,
                                (const bf16_t*)k, (const bf16_t*)v, (float*)ws, kv_len_dev, kv_len_host, kv_rows, kv_stride_h,
@@ -172,7 +177,7 @@ int skv_launch_sparse_attention(const void* q, const void* k, const void* v, voi
         return SKV_OK;
     }
     const size_t smem = (size_t)AT_GROUPS * G * (AT_D + 2) * sizeof(float) + (slots ? (size_t)n_slots * sizeof(int) : 0) +
-                        (G == 8 && !slots ? SKV_ATTN_MFMA_LDS_FLOATS * sizeof(float) : 0);
+                        ((G == 8 || G == 4) && !slots ? SKV_ATTN_MFMA_LDS_FLOATS * sizeof(float) : 0);
 #define SKV_AT_L(GG, LL)                                                                                        \
     do {                                                                                                        \
         static size_t attr_bytes[64] = {};                                                                      \

@@ -375,7 +375,10 @@ def test_rebuild_keys(glm):
 @pytest.mark.parametrize("bs,Hq,Hkv,kv_len,splits", [(1, 32, 8, 2497, 32), (2, 32, 8, 300, 8), (1, 32, 4, 2560, 32),
                                                      (1, 8, 8, 77, 16), (1, 32, 8, 5, 32),
                                                      # G = 8: the Q.K^T-on-MFMA body; ragged ranges, more splits than keys
-                                                     (1, 16, 2, 77, 16), (2, 16, 2, 1000, 60), (1, 32, 4, 9, 32)])
+                                                     (1, 16, 2, 77, 16), (2, 16, 2, 1000, 60), (1, 32, 4, 9, 32),
+                                                     # more than 64 (batch, head) pairs: G = 4 takes Q.K^T on the MFMA with P.V
+                                                     # on the VALU (HBM-bound batches), G = 8 stays all-MFMA
+                                                     (9, 32, 8, 300, 3), (17, 32, 4, 131, 2)])
 def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
     g = torch.Generator().manual_seed(kv_len)
     rows = kv_len + 50
