@@ -582,6 +582,34 @@ def test_captured_batched_step_replays_like_eager(case):
     assert 0 < hits < c2.block_num * c2.select_sets * m2.num_layers
 
 
+@pytest.mark.parametrize("glm", [False, True])
+@torch.inference_mode()
+def test_call_order_shortcuts_change_no_bit(glm):
+    """The reference-shaped one-token path takes two shortcuts inside its own methods: the RoPE launch pushes the rotated K and
+    V into the cache row (update_kv_cache then only books) and a synthetic-query hook rides in that launch's q-override slot.
+    Against the same model with both shortcuts off (separate update launch, separate hook launch): identical tokens, logits
+    and cache bytes."""
+    m1, llama = _make(glm=glm)
+    m2, _ = _make(glm=glm)
+    m2.kv_cache.incoming_rows_writable = lambda n: False           # -> scratch rows + skv_update_kv_cache
+    w1, w2 = llama.QueryWalk(m1, step=0.3, seed=9), llama.QueryWalk(m2, step=0.3, seed=9)
+    m1.query_hook = w1
+    m2.query_hook = lambda layer_idx, q: w2(layer_idx, q)          # no qb_layers attribute -> the hook is a launch of its own
+    t1 = t2 = torch.tensor([[17]], device=DEV)
+    for _ in range(4):
+        w1.advance(); w2.advance()
+        l1 = m1.inference(t1, m1.get_ctx(t1))
+        l2 = m2.inference(t2, m2.get_ctx(t2))
+        assert torch.equal(l1, l2)
+        t1, t2 = l1[:, -1].argmax(-1, keepdim=True), l2[:, -1].argmax(-1, keepdim=True)
+    torch.cuda.synchronize()
+    c1, c2 = m1.kv_cache, m2.kv_cache
+    assert c1.gen_offset == c2.gen_offset == 4 and c1.kv_offset == c2.kv_offset
+    assert torch.equal(c1.position_ids, c2.position_ids)
+    assert torch.equal(c1.k_cache_buffer.view(torch.int16), c2.k_cache_buffer.view(torch.int16))
+    assert torch.equal(c1.v_cache_buffer.view(torch.int16), c2.v_cache_buffer.view(torch.int16))
+
+
 @torch.inference_mode()
 def test_capture_refuses_the_torch_topk_fallback_at_batch_2():
     """A logit row the native sampler does not take (top_k > 64) would put torch.topk into the captured step; at bs > 1

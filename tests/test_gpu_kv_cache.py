@@ -30,6 +30,33 @@ def _build(case):
     return cache, c, inp
 
 
+def test_update_kv_cache_native_launch_matches_the_sliced_copies():
+    """update_kv_cache (kv_cache.py:1227-1271) as ONE native launch: the new K rows (contiguous) and V rows (a strided view of
+    the fused projection, as the host model hands them over) land in rows [sparse_end + gen, ...) of both buffers, everything
+    else keeps its bytes; rows past the end of the buffer are dropped like the reference's zero-length slice."""
+    cache, c, inp = _build("llama_small")
+    kv, D = c["kv_heads"], c["head_dim"]
+    g = torch.Generator(device=DEV).manual_seed(4)
+    rows = cache.k_cache_buffer.shape[-2]
+    slack = rows - cache.sparse_end
+    for incoming, gen in ((1, 0), (2, 5), (3, slack - 1)):
+        cache.gen_offset = gen
+        k0, v0 = cache.k_cache_buffer[0].clone(), cache.v_cache_buffer[0].clone()
+        fused = torch.randn(1, incoming, (32 + 2 * kv) * D, device=DEV, generator=g).bfloat16()
+        k_new = torch.randn(1, kv, incoming, D, device=DEV, generator=g).bfloat16()
+        v_new = fused[..., (32 + kv) * D:].view(1, incoming, kv, D).transpose(1, 2)          # [1, kv, incoming, D], strided
+        assert incoming == 1 or not v_new.is_contiguous()
+        cache.update_kv_cache(k_new, v_new, 0)
+        torch.cuda.synchronize()
+        lo = cache.sparse_end + gen
+        n = min(incoming, rows - lo)
+        k0[:, :, lo:lo + n] = k_new[:, :, :n]
+        v0[:, :, lo:lo + n] = v_new[:, :, :n]
+        assert_bits_equal(cache.k_cache_buffer[0], k0, f"K buffer, incoming {incoming} at row {lo}")
+        assert_bits_equal(cache.v_cache_buffer[0], v0, f"V buffer, incoming {incoming} at row {lo}")
+        assert cache.gen_offset == gen + incoming              # (the fixture cache has one layer: the last one advances)
+
+
 def test_pinned_v_table_outlives_the_cache_through_its_views():
     import gc
     cache, c, inp = _build("llama_small")
