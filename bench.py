@@ -715,9 +715,13 @@ def main():
                 gc.collect(); torch.cuda.empty_cache()
                 model, cfg2, ctx2, budget2, tb = build_model(wl, args, rank, dev)
                 r = run_decode(model, args, ctx2, 24, 4, args.walk_step, seed=99 + rank)
+                rf = measure_score_kernel(model)          # the landmark scan of THIS workload's shape against the HBM roof
                 sec.append(dict(workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
                                 value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1)))
+                                chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1),
+                                scan_roofline={"us_per_launch": round(rf["us_per_launch"], 3), "algorithmic_bytes_per_launch": rf["algorithmic_bytes"],
+                                               "achieved": round(rf["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(rf["gbs"] / HBM_PEAK_GBS, 4)}))
             out["secondary"] = sec
             # the same workload with 512 resident chunk slots per head (HBM is plentiful, the link is the roof): identical
             # selections and outputs, fewer chunks over PCIe.  Not the headline: the reference's resident set is the last

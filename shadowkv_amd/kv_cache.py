@@ -60,7 +60,8 @@ def pinned_host_tensor(shape, dtype):
     if rc != 0 or not p.value:
         raise MemoryError(f"skv_host_alloc({nbytes} bytes of pinned host memory) failed: {lib().skv_last_error().decode()}")
     buf = (ctypes.c_char * nbytes).from_address(p.value)
-    weakref.finalize(buf, lib().skv_host_free, p.value)
+    fin = weakref.finalize(buf, lib().skv_host_free, p.value)
+    fin.atexit = False      # at interpreter exit the HIP runtime may already be gone: the OS reclaims the pages
     return torch.frombuffer(buf, dtype=dtype).view(shape)
 
 

@@ -11,10 +11,12 @@ from test_gpu_kv_cache import _headline_cache
 
 def main():
     hit = float(sys.argv[1]) if len(sys.argv) > 1 else 0.67
-    cache, cs, g = _headline_cache(8, False, L=65536)
+    kv = int(sys.argv[2]) if len(sys.argv) > 2 else 8            # 8: Llama (G = 4); 4: GLM-4 (G = 8, GLM RoPE)
+    glm = kv == 4
+    cache, cs, g = _headline_cache(kv, glm, L=65536)
     L = _lib.lib()
     L.skv_debug_rb_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    S, kv = cache.select_sets, 8
+    S = cache.select_sets
     q = (torch.randn(1, 32, 1, 128, device="cuda:0", generator=g) * 1.5).bfloat16()
     kv_len = cache.sparse_end + 3
     lm_idx = cache.k_landmark_idx[0][0].cpu()
@@ -37,11 +39,11 @@ def main():
         L.skv_debug_rb_stamps(buf.ctypes.data, 1)
         st = buf.reshape(16, 128, 8).astype(np.int64)
         t0 = st[st > 0].min()
-        tiles = st[:8, :32]; att = st[:8, 32:56]
+        tiles = st[:kv, :32]; att = st[:kv, 32:32 + cache._overlap_splits()]
         live = tiles[..., 0] > 0
         rel = lambda a: (a - t0) / 100.0
         names = ["start", "host loads issued", "K tile ready", "scores done", "V arrived", "partials done", "end"]
-        print(f"run {it}: hit {hit}: {int(live.sum())} live tiles; kernel span {rel(st.max()):.2f} us")
+        print(f"run {it}: {kv} KV heads, hit {hit}: {int(live.sum())} live tiles; kernel span {rel(st.max()):.2f} us")
         for i, n in enumerate(names):
             v = rel(tiles[..., i][live])
             print(f"   tile WGs  {n:<18} min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f}")

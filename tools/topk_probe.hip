@@ -9,7 +9,9 @@
 #include <vector>
 int main(int argc, char** argv) {
     const bool inplace = argc > 1 && !strcmp(argv[1], "inplace");
-    const int B = 8, N = 15560, S = 256, stride = (N + 7) & ~7;
+    // TOPK_PROBE_N / TOPK_PROBE_B: another shape (GLM-4 at 200K: N 25544, B 4; the 1M-token context: N 131056, B 8)
+    const int B = getenv("TOPK_PROBE_B") ? atoi(getenv("TOPK_PROBE_B")) : 8, N = getenv("TOPK_PROBE_N") ? atoi(getenv("TOPK_PROBE_N")) : 15560;
+    const int S = 256, stride = (N + 7) & ~7;
     const int R = argc > 6 ? atoi(argv[6]) : S;
     const bool nolm = getenv("TOPK_PROBE_NOLM") != nullptr;   // identity slot -> id map: no id gathers at all     // argv[6]: resident slots per head (> S: least-recently-selected replacement)
     std::vector<uint16_t> sc((size_t)B * stride);
