@@ -667,6 +667,13 @@ def main():
             if ref_set and bs == 1:
                 extras["value_call_order"] = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step,
                                                             seed=99 + rank)
+                if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
+                    r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
+                                   seed=99 + rank)
+                    extras["value_eager"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
+                                                 note="--mode eager: the fused 9-launch step issued from Python every step (no hipGraph)")
+                    extras["value_call_order"]["fraction_of_eager_fused"] = round(extras["value_call_order"]["value"] / r["value"], 3)
             if ref_set and args.layout == "inplace" and args.query_mode == "walk":
                 extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
         traffic = None

@@ -75,17 +75,27 @@ struct AttnRole {
 // that rebuilt the K rows of 8 miss chunks holds them in LDS and holds the chunks' V rows in REGISTERS (the landing loads:
 // thread (rsub, unit) has 16 B = 8 dims of token unit / 16 of chunk 2k + rsub, i.e. a 16-lane group holds whole V rows),
 // so it attends the tile right there for all G query heads of the KV head and emits one record (acc[128], m, l) per
-// head - the miss rows are never read back from HBM by a second pass.  The scores and softmax weights are computed while
-// the host loads are still in flight; only p * V waits for them.  Same arithmetic as skv_attn_partial_body (one batch of
-// 4 keys per 16-lane group).  Rows below `first_live` are resident (hit) rows: not attended here (the split pass has them).
+// head - the miss rows are never read back from HBM by a second pass.
+// Round 3: everything that can happen BEFORE the V rows are back happens while the host loads are in flight - q.k for the
+// group's 4 rows (VALU, K tile and q in LDS), the tile-wide maximum per head, the softmax weights, written to LDS as the
+// bf16 A operand P[g][key] of an MFMA -, so that what remains behind the PCIe round trip is: V registers -> cache and ->
+// an LDS image, one barrier, out[g][d] = sum_key P[g][key] V[key][d] as 4 v_mfma_f32_16x16x32_bf16 per landing wave (two
+// 16-dim column blocks x two 32-key steps; V comes back k-major through ds_read_b64_tr_b16), and the record.  No per-group
+// partials and no merge of 16 of them any more: in-kernel stamps put the part behind the last V row at 1.6 us (G = 4) /
+// 3.2 us (G = 8) before (profiles/r03_fetch_stamps.txt).  P is rounded to bf16 for the MFMA as in the standalone pass.
+// Rows below `first_live` are resident (hit) rows: weight 0 here (the split pass has them).
+// LDS (over the SV staging area, dead once the rebuild waves' MFMA phase is over):
+#define TA_V_BYTES (64 * 256)                    // V image [64 rows][256 B], T10 swizzle
+#define TA_P_BYTES (16 * 64 * 2)                 // P [16 head rows (>= G: zero)][64 keys] bf16
 template <int G>
 struct TileAttn {
-    float p[4][G], mn[G], lsum[G];
+    float sc[4][G];                              // scores of the group's 4 rows (the 16 lanes of a group hold the same values)
 
-    // phase A: q . k for the group's 4 rows (K tile and q in LDS), softmax weights relative to the group maximum.
+    // phase A1: q . k for the group's 4 rows, group maximum per head -> s_gmax[grp][g].
     // vt = thread index among the 256 attention threads (waves 4..7 of the workgroup)
-    __device__ __forceinline__ void scores(const bf16_t* q, const unsigned char* sK, int first_live, float scale, int vt) {
-        const int sub = vt & 15, rsub = vt >> 7, g8 = (vt & 127) >> 4;
+    __device__ __forceinline__ void scores(const bf16_t* q, const unsigned char* sK, int first_live, float scale, int vt,
+                                           float* s_gmax) {
+        const int sub = vt & 15, rsub = vt >> 7, g8 = (vt & 127) >> 4, grp = vt >> 4;
         float qf[G][8];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -96,7 +106,6 @@ struct TileAttn {
                 qf[g][2 * j + 1] = bf_hi(wq[j]) * scale;
             }
         }
-        float sc[4][G];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = (2 * k + rsub) * 8 + g8;                 // the row whose V piece this thread loaded as lv[k]
@@ -119,74 +128,73 @@ struct TileAttn {
             }
         }
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m = fmaxf(m, sc[k][g]);
-            mn[g] = m;
-            float l = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                p[k][g] = sc[k][g] == -INFINITY ? 0.f : __expf(sc[k][g] - m);
-                l += p[k][g];
-            }
-            lsum[g] = l;
-        }
+        for (int g = 0; g < G; ++g)
+            if (sub == g) s_gmax[grp * G + g] = fmaxf(fmaxf(sc[0][g], sc[1][g]), fmaxf(sc[2][g], sc[3][g]));
     }
 
-    // phase B: p * V from the landing registers -> the group's partial (acc[128], m, l) per query head in LDS
-    __device__ __forceinline__ void pv(const u32x4 (&lv)[4], const bool (&lact)[4], float* s_part_raw, int vt) {
-        const int sub = vt & 15, grp = vt >> 4;
-        float (*s_part)[G][AT_D + 2] = reinterpret_cast<float (*)[G][AT_D + 2]>(s_part_raw);
+    // phase A2 (behind a barrier): tile maximum per head, weights relative to it -> P (bf16) and the group's sum -> s_gl
+    __device__ __forceinline__ void weights(int vt, const float* s_gmax, bf16_t* s_P, float* s_gl, float* s_M) {
+        const int sub = vt & 15, rsub = vt >> 7, g8 = (vt & 127) >> 4, grp = vt >> 4;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float acc[8];
+            float M = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_gmax[r * G + g]);      // (finite: the tile has a live row)
+            if (sub == g) {                                     // one lane of the group per head
+                float l = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (lact[k]) {                                      // (dead rows: p == 0, lv[k] is a filler row)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[2 * j] = __builtin_fmaf(p[k][g], bf_lo(lv[k][j]), acc[2 * j]);
-                        acc[2 * j + 1] = __builtin_fmaf(p[k][g], bf_hi(lv[k][j]), acc[2 * j + 1]);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const float pk = sc[k][g] == -INFINITY ? 0.f : __expf(sc[k][g] - M);
+                    l += pk;
+                    s_P[g * 64 + (2 * k + rsub) * 8 + g8] = f2bf(pk);
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s_part[grp][g][8 * sub + j] = acc[j];
-            if (sub == 0) {
-                s_part[grp][g][AT_D] = mn[g];
-                s_part[grp][g][AT_D + 1] = lsum[g];
+                s_gl[grp * G + g] = l;
+                if (grp == 0) s_M[g] = M;
             }
         }
     }
 };
 
-// merge of the 16 group partials of a tile: one record per query head, all `nthreads` threads of the workgroup
+// phase B of the tile attention, landing waves only (lw = 0..3), behind the barrier that follows the V image: two 16-dim
+// column blocks per wave, out[g][d] over the tile's 64 keys, record (acc[128], m, l) per head.
 template <int G>
-__device__ __forceinline__ void skv_tile_merge(const float* s_part_raw, float* __restrict__ rec, size_t rec_stride_g, int tid,
-                                               int nthreads) {
-    const float (*s_part)[G][AT_D + 2] = reinterpret_cast<const float (*)[G][AT_D + 2]>(s_part_raw);
-    for (int o = tid; o < G * AT_D; o += nthreads) {
-        const int g = o / AT_D, d = o % AT_D;
-        float M = -INFINITY;
+__device__ __forceinline__ void skv_tile_pv_mfma(const unsigned char* s_v, const bf16_t* s_P, const float* s_gl, const float* s_M,
+                                                 float* __restrict__ rec, size_t rec_stride_g, int lane, int lw) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 ta_bf16x8;
+    typedef __attribute__((ext_vector_type(4))) float ta_f32x4;
+    const int sub = lane & 15, c4 = lane >> 4, qrow = sub >> 2, pp = sub & 3;
+    const uint32_t sv_base = skv_lds_addr_of(s_v);
+    ta_bf16x8 a[2];
 #pragma unroll
-        for (int r = 0; r < AT_GROUPS; ++r) M = fmaxf(M, s_part[r][g][AT_D]);
-        float a = 0.f, L = 0.f;
+    for (int ks = 0; ks < 2; ++ks)                               // A[row g = sub][k = key 32 ks + 8 c + j]
+        a[ks] = __builtin_bit_cast(ta_bf16x8, *reinterpret_cast<const u32x4*>(s_P + sub * 64 + 32 * ks + 8 * c4));
 #pragma unroll
-        for (int r = 0; r < AT_GROUPS; ++r) {
-            const float mr = s_part[r][g][AT_D];
-            const float wgt = (mr == -INFINITY) ? 0.f : __expf(mr - M);
-            a = __builtin_fmaf(s_part[r][g][d], wgt, a);
-            L = __builtin_fmaf(s_part[r][g][AT_D + 1], wgt, L);
+    for (int h = 0; h < 2; ++h) {
+        const int nb = 2 * lw + h;
+        ta_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // B[k = key 32 ks + 8 c + j][n = sub]: two 4-row x 16-column blocks, rows 32 ks + 8 c (+ 4) .. ; lane 4 q + p of the
+            // 16-lane group supplies row r0 + q, columns 4 p .. 4 p + 3 (chunk 2 nb + (p >> 1))
+            const int r0 = 32 * ks + 8 * c4;
+            const u32x2 b0 = skv_ds_read_tr16(sv_base + skv_v_off(r0 + qrow, 2 * nb + (pp >> 1)) + 8 * (pp & 1));
+            const u32x2 b1 = skv_ds_read_tr16(sv_base + skv_v_off(r0 + 4 + qrow, 2 * nb + (pp >> 1)) + 8 * (pp & 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], __builtin_bit_cast(ta_bf16x8, (u32x4){b0[0], b0[1], b1[0], b1[1]}), o, 0, 0, 0);
         }
-        float* dst = rec + (size_t)g * rec_stride_g;
-        dst[d] = a;
-        if (d == 0) {
-            dst[AT_D] = M;
-            dst[AT_D + 1] = L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                            // o[i] = out[g = 4 c + i][d = 16 nb + sub]
+            const int g = 4 * c4 + i;
+            if (g < G) rec[(size_t)g * rec_stride_g + 16 * nb + sub] = o[i];
         }
+    }
+    if (lw == 0 && lane < G) {                                   // m and l of head g = lane
+        float L = 0.f;
+#pragma unroll
+        for (int r = 0; r < AT_GROUPS; ++r) L += s_gl[r * G + lane];
+        rec[(size_t)lane * rec_stride_g + AT_D] = s_M[lane];
+        rec[(size_t)lane * rec_stride_g + AT_D + 1] = L;
     }
 }
 
@@ -318,9 +326,14 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
 
     // Attention role present (in-place layout, C == 8, S % 8 == 0): waves 4..7 LAND the V chunks of the tile's 8 slots and
     // attend the finished tile (TileAttn) from those registers; waves 0..3 rebuild the K tile below.
-    constexpr size_t part_bytes = (size_t)AT_GROUPS * (AG > 0 ? AG : 1) * (AT_D + 2) * sizeof(float);
-    // group partials: over the SV staging area (dead after the MFMA phase) when they fit, else behind the K tile and q
-    float* const s_part = reinterpret_cast<float*>(part_bytes <= (size_t)RB_D * RB_SV_PITCH ? smem : sOut + RB_ROWS * RB_OUT_PITCH + AG * 256);
+    // tile-attention scratch over the SV staging area (dead once the MFMA phase of the rebuild waves is over, barrier (2)):
+    // V image | P | group maxima | group sums | tile maxima
+    unsigned char* const s_v = smem;
+    bf16_t* const s_P = reinterpret_cast<bf16_t*>(smem + TA_V_BYTES);
+    float* const s_gmax = reinterpret_cast<float*>(smem + TA_V_BYTES + TA_P_BYTES);
+    float* const s_gl = s_gmax + AT_GROUPS * (AG > 0 ? AG : 1);
+    float* const s_M = s_gl + AT_GROUPS * (AG > 0 ? AG : 1);
+    static_assert(TA_V_BYTES + TA_P_BYTES + (2 * AT_GROUPS + 1) * 8 * sizeof(float) <= (size_t)RB_D * RB_SV_PITCH, "tile-attention scratch");
     const bf16_t* const q_lds = reinterpret_cast<const bf16_t*>(sOut + RB_ROWS * RB_OUT_PITCH);     // [G][128] behind the K tile
     if constexpr (AG > 0) {
         float* const rec = ar.ws + ((size_t)bh * AG * ar.rec_splits + ar.splits + bx) * AT_REC;
@@ -358,23 +371,28 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
             }
             asm volatile("" ::: "memory");
             RB_STAMP(1, 256);
-            __syncthreads();                                   // (2) accumulators in LDS
+            __syncthreads();                                   // (2) accumulators in LDS: the SV staging area is dead
+            reinterpret_cast<u32x2*>(s_P)[vt] = (u32x2){0u, 0u};   // P rows of the padding heads (and everything else) = 0
             __syncthreads();                                   // (3) rotated K tile (and q) in LDS
             RB_STAMP(2, 256);
             TileAttn<AG> ta;
-            ta.scores(q_lds, sOut, cnt * 8 - i0, ar.scale, vt);                      // the host loads are still in flight
+            ta.scores(q_lds, sOut, cnt * 8 - i0, ar.scale, vt, s_gmax);              // the host loads are still in flight
+            __syncthreads();                                   // (3a) group maxima in LDS
+            ta.weights(vt, s_gmax, s_P, s_gl, s_M);                                  // still in flight
             RB_STAMP(3, 256);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)                        // V chunks of the live slots into the cache ...
+            for (int k = 0; k < 4; ++k) {                      // V chunks of the live slots into the cache and, every row, into
                 if (lact[k]) v_buf[(long long)bh * v_stride_u128 + v_off_u128 + (long long)lslot[k] * 128 + unit] = lv[k];
+                // the LDS image the MFMA reads k-major (rows of dead chunks are filler rows of the cache: weight 0)
+                *reinterpret_cast<u32x4*>(s_v + skv_v_off((2 * k + rsub) * 8 + (unit >> 4), unit & 15)) = lv[k];
+            }
 #ifdef SKV_RB_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RB_STAMP(4, 256);
 #endif
-            ta.pv(lv, lact, s_part, vt);                       // ... and the same registers feed p * V
-            __syncthreads();                                   // (4)
+            __syncthreads();                                   // (4) V image, P, group sums in LDS
             RB_STAMP(5, 256);
-            skv_tile_merge<AG>(s_part, rec, rec_stride, tid, 512);
+            skv_tile_pv_mfma<AG>(s_v, s_P, s_gl, s_M, rec, rec_stride, tid & 63, (tid >> 6) - 4);
             RB_STAMP(6, 256);
             return;
         }
@@ -527,9 +545,8 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
     }
     if constexpr (AG > 0) {
         __syncthreads();                                       // (3) rotated K rows of the tile are in LDS
-        __syncthreads();                                       // (4) the attention waves' group partials are in LDS
-        skv_tile_merge<AG>(s_part, ar.ws + ((size_t)bh * AG * ar.rec_splits + ar.splits + bx) * AT_REC,
-                           (size_t)ar.rec_splits * AT_REC, tid, 512);
+        __syncthreads();                                       // (3a) the landing waves' group maxima
+        __syncthreads();                                       // (4) their V image and weights: they finish the tile alone
     }
 }
 
@@ -572,11 +589,10 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
         ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->kv_rows,
                       attn->splits, attn->rec_splits, attn->resident_sets * C, attn->scale};
         attn_g = attn->G;
-        // fused tile: SV staging | K tile (| group partials when they do not fit over the SV staging area)
+        // fused tile: SV staging (later: the tile attention's V image / weights) | K tile | q
         const size_t part = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float);
-        smem_all = (size_t)RB_D * RB_SV_PITCH + (size_t)RB_ROWS * RB_OUT_PITCH + (size_t)attn_g * 256 /* q */ +
-                   (part <= (size_t)RB_D * RB_SV_PITCH ? 0 : part);
-        const size_t need = part + (size_t)S * sizeof(int);    // resident-rows role: partials + the slot list
+        smem_all = (size_t)RB_D * RB_SV_PITCH + (size_t)RB_ROWS * RB_OUT_PITCH + (size_t)attn_g * 256 /* q */;
+        const size_t need = part + (size_t)S * sizeof(int);    // resident-rows role: group partials + the slot list
         if (need > smem_all) smem_all = need;
         // ONE workgroup per CU (LDS request above half of the 160 KB): measured with in-kernel stamps and A/B runs, a CU
         // with host-memory loads outstanding serves its other memory traffic only when they return, so a second workgroup

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from util import attention_tolerance, ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step, check_topk_against_reference, record_parity, REBUILD_FLIP_BOUND
+from util import attention_tolerance, record_attention_parity, ALPHA, assert_bits_equal, ulp_diff_bf16, make_selection_step, check_topk_against_reference, record_parity, REBUILD_FLIP_BOUND
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -403,7 +403,9 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
         # tolerance: fp16-level 1e-3 relative (north_star) + half a bf16 ulp of the output rounding (+ the bf16 softmax
         # weights of the all-MFMA pass, which small (batch, head) counts with G = 4 / 8 take)
         tol = attention_tolerance(o0f, o0abs)
-        assert bool(((o1 - o0f).abs() <= tol).all()), f"max excess {float(((o1 - o0f).abs() - tol).max())}"
+        err = (o1 - o0f).abs()
+        record_attention_parity(f"test_sparse_attention[{bs}-{Hq}-{Hkv}-{kv_len}-{splits}]", err, o0f, o0abs)
+        assert bool((err <= tol).all()), f"max excess {float((err - tol).max())}"
     # kv_len past the rows a head owns: refused from the host, clamped from the device (never reads the next head)
     a = (qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), ws.data_ptr())
     assert L.lib().skv_sparse_attention(*a, 0, rows + 1, rows, rows * 128, bs, Hq, Hkv, 128, splits, scale, _stream()) == -1

@@ -34,11 +34,11 @@ def ulp_diff_bf16(a, b):
 REBUILD_FLIP_BOUND = 5e-5
 
 
-def open_parity_record():
+def open_parity_record(name="rebuild_parity.txt"):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    return open(os.path.join(root, "gpurun_out", "rebuild_parity.txt"), "a")
+    return open(os.path.join(root, "gpurun_out", name), "a")
 
 
 def attention_tolerance(ref32, absv32=None):
@@ -51,6 +51,18 @@ def attention_tolerance(ref32, absv32=None):
     if absv32 is not None:
         tol = tol + 2.0 ** -9 * absv32
     return tol
+
+
+def record_attention_parity(test, err, ref32, absv32):
+    """Appends to gpurun_out/attention_parity.txt how much of the attention bound a result uses: the largest |error| relative to
+    the f32-weights bound (1e-3 |ref| + half a bf16 ulp + 1e-5) and relative to the bound with the bf16-weights term."""
+    b0, b1 = attention_tolerance(ref32), attention_tolerance(ref32, absv32)
+    try:
+        with open_parity_record("attention_parity.txt") as f:
+            f.write(f"{test:56s} values {err.numel():8d}  max |err| {float(err.max()):.3e}  max err / bound(f32 P) {float((err / b0).max()):6.3f}"
+                    f"  max err / bound(bf16 P) {float((err / b1).max()):6.3f}  values over the f32-P bound {int((err > b0).sum())}\n")
+    except OSError:
+        pass
 
 
 def record_parity(test, d, where="K rebuild"):

@@ -42,7 +42,7 @@ def main():
         tiles = st[:kv, :32]; att = st[:kv, 32:32 + cache._overlap_splits()]
         live = tiles[..., 0] > 0
         rel = lambda a: (a - t0) / 100.0
-        names = ["start", "host loads issued", "K tile ready", "scores done", "V arrived", "partials done", "end"]
+        names = ["start", "host loads issued", "K tile ready", "weights done", "V arrived", "V image + barrier", "end"]
         print(f"run {it}: {kv} KV heads, hit {hit}: {int(live.sum())} live tiles; kernel span {rel(st.max()):.2f} us")
         for i, n in enumerate(names):
             v = rel(tiles[..., i][live])
