@@ -74,8 +74,7 @@ struct TailGeom {                                                          // wa
 __device__ __forceinline__ int tl_pad(int t) { return (t + TL_RING - 1) / TL_RING * TL_RING; }
 
 // One batch = 8 segments of 1 KiB (64 lanes x 16 B) of ONE row: all of a 4096-element row, a quarter of a down-projection
-// row.  (Whole rows per batch matter: the waves run in step, and batches of half rows - 2 rows x 4 KiB - left every other
-// 4 KiB of the address space untouched at any one time: 3.0 TB/s instead of 6.)  Every load is unconditional (a batch that
+// row.  Every load is unconditional (a batch that
 // does not exist, a segment past the row and the lanes past a partial last segment read the first KiB of Wo instead, an L2
 // hit): hipcc's s_waitcnt counts then stay exact, a conditional load would make every wait a vmcnt(0).
 //   stage 0 (O):       unit = row,          1 batch per unit
