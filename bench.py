@@ -100,6 +100,9 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
         llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
     else:
         llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
+    if (not full and args.early_fetch and args.batch == 1 and args.v_table == "host" and model.kv_cache.can_overlap_attention()
+            and model.kv_cache.early_fetch_supported()):
+        model.kv_cache.enable_early_fetch(early_max=None if args.early_fetch < 0 else args.early_fetch, margin=args.early_margin)
     torch.cuda.synchronize()
     return model, cfg, ctx, budget, time.perf_counter() - t0
 
@@ -479,6 +482,7 @@ def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
     events around every layer's fetch launch; bytes = the miss chunks of exactly those launches (per-layer hit counts)."""
     from shadowkv_amd import llama
     cache = model.kv_cache
+    early, cache._early = getattr(cache, "_early", None), None     # every miss byte of the measured launches crosses the link
     rewind(model, ctx)
     walk = llama.QueryWalk(model, step=walk_step, seed=seed)
     tok = torch.randint(0, model.cfg.vocab_size, (model.batch_size, 1), device=model.device)
@@ -498,13 +502,15 @@ def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
         n += len(ev)
         miss += int(cache.block_num * cache.select_sets * model.num_layers - int(cache._cnts_layers.sum()))
     rewind(model, ctx)
+    cache._early = early
     nbytes = miss * cache.chunk_size * cache.head_dim * 2
     gbs = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
     return dict(us_per_layer=round(us / max(n, 1), 2), miss_chunks_per_layer=round(miss / max(n, 1), 1),
                 bytes_per_layer=int(nbytes / max(n, 1)), pcie_gbs=round(gbs, 2),
                 frac_of_dma_ceiling=round(gbs / DMA_CEILING_GBS, 3), dma_ceiling_gbs=DMA_CEILING_GBS,
                 frac_of_spec=round(gbs / PCIE_PEAK_GBS, 3), launches=n,
-                how="torch.cuda.Event pair around every layer's fetch launch over %d eager decode steps" % steps)
+                how="torch.cuda.Event pair around every layer's fetch launch over %d eager decode steps%s" % (
+                    steps, "" if early is None else " (early fetch off for this measurement: all miss bytes cross the link inside the launch)"))
 
 
 def run_call_order(model, ctx, steps, warmup, walk_step, seed):
@@ -587,6 +593,10 @@ def main():
                     help="chunk slots kept resident per head (default: select_sets = budget / 8, the reference's resident "
                          "set; larger: a selected chunk found in any slot is a hit, least recently selected slots are "
                          "replaced - same outputs, fewer chunks over PCIe; in-place layout only)")
+    ap.add_argument("--early-fetch", type=int, default=-1,
+                    help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
+                         "top-k; -1 = the default for the shape (32 for G <= 4, 96 for G = 8), 0 = off")
+    ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
@@ -676,6 +686,32 @@ def main():
                     extras["value_call_order"]["fraction_of_eager_fused"] = round(extras["value_call_order"]["value"] / r["value"], 3)
             if ref_set and args.layout == "inplace" and args.query_mode == "walk":
                 extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
+            if cache._early is not None and args.mode == "graph":
+                # the speculative early V fetch: what it pulled / what the fetch launch then read from staging (last layer of
+                # one more eager step), and the same captured run without it
+                from shadowkv_amd import llama
+                ea = cache._early
+                stats = None
+                try:
+                    rewind(model, ctx)
+                    walk2 = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
+                    tok2 = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
+                    for _ in range(4):
+                        walk2.advance()
+                        tok2 = model.decode_step(tok2, temperature=0.6, q_table=walk2.qb)
+                    torch.cuda.synchronize()
+                    stats = cache.early_fetch_stats(model.num_layers - 1)
+                except Exception as e:
+                    print(f"[bench] early-fetch statistics failed: {e}", file=sys.stderr)
+                cache._early = None
+                r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                cache._early = ea
+                extras["early_fetch"] = dict(
+                    chunks_per_head=ea["E"], margin=ea["margin"],
+                    last_layer_one_step=None if stats is None else dict(pulled_early=stats[0], read_from_staging=stats[1], misses=stats[2]),
+                    value_without=dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]),
+                    note="speculative early V fetch (csrc/skv_early.h): chunks predicted to miss are pulled over PCIe by an extra "
+                         "workgroup of the top-k launch; identical results (tests/test_gpu_kv_cache.py)")
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
         if os.path.exists(pmc_path) and args.workload == "llama31_122k" and bs == 1:
@@ -695,7 +731,8 @@ def main():
                                    + ("" if args.pin_hit_rate is None else f" (chunk hit rate pinned to {args.pin_hit_rate})"),
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
             "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
-            "launch_mode": head["mode"], "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
+            "launch_mode": head["mode"], "early_fetch_chunks_per_head": None if full or cache._early is None else cache._early["E"],
+            "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
             "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa, "per_rank": per_rank,
             "parity_note": "selection path bit-exact against the CPU oracle; top-k stage pinned to the reference's torch.topk "
                            "(set-equal modulo ties); scoring vs the reference's CUTLASS softmax is pinned by bound only "

@@ -341,6 +341,45 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, int resident_sets, float scale, skv_stream_t stream);
 
+/* ---- speculative early V fetch (in-place layout) -------------------------------------------------------------------
+ * Which chunks a step will MISS is predictable as soon as the scan has produced the logits: a landmark slot whose logit
+ * reaches the previous step's k-th value (in logit space, per query head) and whose chunk is not resident.  With an early
+ * state, skv_select_chunks_inplace_early flags those slots in the scan launch, turns the flags into a list of up to
+ * early_max non-resident chunks per (batch, head) in one extra workgroup of the normalise launch, and pulls them from the
+ * pinned host table into an HBM staging buffer in one extra workgroup of the top-k launch - PCIe works while the top-k
+ * runs; no extra launch, no extra stream.  skv_fetch_kv_attn_inplace_early then reads every staged miss chunk from HBM and
+ * only the rest over PCIe.  Results are IDENTICAL to skv_select_chunks_inplace + skv_fetch_kv_attn_inplace (staged bytes
+ * are the host table's bytes; a wrong prediction costs PCIe bytes only, at most early_max chunks per head).  No reference
+ * counterpart: the reference fetches after its top-k (/root/reference/models/kv_cache.py:1059-1106).
+ * early_state: skv_early_state_bytes(...) bytes of device memory PER LAYER, initialised once with skv_early_state_init;
+ * n_chunks = chunks per head of the host table (ids in landmark_idx are < n_chunks); early_max <= 128; margin is added to
+ * the logit thresholds (0: flag what would have made the previous top-k; > 0: fewer).  n_landmarks <= 65,536,
+ * resident_sets <= 256, n_chunks <= 262,144; other shapes: SKV_ERR_UNSUPPORTED (-2), use the plain pair.
+ * The two calls are a PAIR: a state whose last step was not consumed by skv_fetch_kv_attn_inplace_early may still be used (the
+ * next skv_select_chunks_inplace_early rewrites it), but skv_fetch_kv_attn_inplace_early must only follow the
+ * skv_select_chunks_inplace_early of the same step and state.
+ * skv_early_state_offsets: byte offsets of the state's regions (diagnostics): 0 thresholds f32 [B][G], 1 finals f32
+ * [B][G][2], 2 flag counts i32 [B][T], 3 flagged slots i32 [B][T][16], 4 pulled count i32 [B], 5 pulled chunk ids i32
+ * [B][early_max], 6 staging index per chunk i16 [B][n_chunks], 7 staging [B][early_max][2048 B]. */
+SKV_EXPORT size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chunks, int early_max);
+SKV_EXPORT int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8);
+SKV_EXPORT int skv_early_state_init(void* state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,
+                         skv_stream_t stream);
+SKV_EXPORT int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const int64_t* landmark_idx,
+                              int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
+                              void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
+                              int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
+                              void* early_state, const void* v_host, long long host_block_stride, int n_chunks,
+                              int early_max, float margin, skv_stream_t stream);
+SKV_EXPORT int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                              const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
+                              void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
+                              int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              int attn_splits, int resident_sets, float scale, const void* early_state, int n_landmarks,
+                              int n_chunks, int early_max, skv_stream_t stream);
+
 /* Merge of the records skv_fetch_kv_attn_inplace left (resident splits + live miss tiles, told by cnts);
  * out [bs][q_heads][128] bf16. */
 SKV_EXPORT int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,

@@ -9,17 +9,18 @@
 
 // launchers (defined in the kernel files)
 int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
-                     float alpha, hipStream_t st);
+                     float alpha, hipStream_t st, const EarlyHooks* hooks = nullptr);
 int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void* P, int B, int m, int N,
                                    hipStream_t st);
 int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
-                                  int score_stride, int B, int G, int N, hipStream_t st);
+                                  int score_stride, int B, int G, int N, hipStream_t st, const EarlyHooks* hooks = nullptr);
 int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st);
 int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                              int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
-                             int B, int N, int S, int R, int32_t* slot_age, hipStream_t st);
+                             int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks = nullptr);
+int skv_launch_early_init(const EarlyState& es, int B, int G, int n_landmarks, int n_chunks, int E, hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, void* temp, const int32_t* offsets, const int32_t* cnts,
                          long long host_len_elems, long long dev_stride_elems, long long dev_off_elems, int B, int S,
                          hipStream_t st);
@@ -292,6 +293,59 @@ int skv_select_chunks_inplace(const void* q, const void* landmarks, const int64_
                                            slot_age, st));
 }
 
+// ---- speculative early V fetch (skv_early.hip) -------------------------------------------------------------------
+size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chunks, int early_max) {
+    if (blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return 0;
+    return skv_carve_early(nullptr, blocks, groups, n_landmarks, n_chunks, early_max).total;
+}
+
+int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8) {
+    if (!out8 || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    const EarlyState e = skv_carve_early(nullptr, blocks, groups, n_landmarks, n_chunks, early_max);
+    const unsigned char* z = nullptr;
+    out8[0] = (const unsigned char*)e.dthr - z;      out8[1] = (const unsigned char*)e.finals - z;
+    out8[2] = (const unsigned char*)e.flag_cnt - z;  out8[3] = (const unsigned char*)e.flag_slot - z;
+    out8[4] = (const unsigned char*)e.early_cnt - z; out8[5] = (const unsigned char*)e.early_ids - z;
+    out8[6] = (const unsigned char*)e.early_of - z;  out8[7] = (const unsigned char*)e.staging - z;
+    return SKV_OK;
+}
+
+int skv_early_state_init(void* state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,
+                         skv_stream_t stream) {
+    if (!state || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    return finish(skv_launch_early_init(skv_carve_early(state, blocks, groups, n_landmarks, n_chunks, early_max), blocks, groups,
+                                        n_landmarks, n_chunks, early_max, (hipStream_t)stream));
+}
+
+int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const int64_t* landmark_idx,
+                                    int64_t* cached_pos_ids, int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts,
+                                    void* workspace, void* softmax_out, int64_t* selected_out, int blocks, int groups,
+                                    int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
+                                    void* early_state, const void* v_host, long long host_block_stride, int n_chunks,
+                                    int early_max, float margin, skv_stream_t stream) {
+    if (!q || !landmarks || !landmark_idx || !cached_pos_ids || !miss_ids || !dst_slots || !cnts || !workspace) return SKV_ERR_ARG;
+    if (!early_state || !v_host || (host_block_stride % 8)) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1 || resident_sets < select_sets) return SKV_ERR_ARG;
+    if (n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
+    // the list (normalise launch) and the pull (second-generation top-k launch) exist for these shapes only; a list that is
+    // published MUST be pulled, so other shapes are refused here instead of degrading silently
+    if (n_landmarks > 65536 || resident_sets > 256 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+    EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
+                  es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
+                  (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
+    int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
+    if (rc != SKV_OK) return rc;
+    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
+                                       n_landmarks, st, &eh);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_topk_resident(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
+                                           selected_out, dst_slots, blocks, n_landmarks, select_sets, resident_sets, slot_age,
+                                           st, &eh));
+}
+
 int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,
                            int32_t* offsets, int32_t* dst_slots, int32_t* cnts, int64_t* selected_out, int blocks,
                            int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, skv_stream_t stream) {
@@ -354,6 +408,28 @@ int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, con
                                      (long long)sparse_start * head_dim, (hipStream_t)stream, nullptr));
 }
 
+static int fetch_kv_attn_inplace_impl(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                              const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
+                              void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
+                              int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              int attn_splits, int resident_sets, float scale, skv_stream_t stream, const short* early_of,
+                              const void* early_staging, int early_chunks, int early_max) {
+    if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache || !q ||
+        !attn_workspace)
+        return SKV_ERR_ARG;
+    if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
+    if (select_sets % 8) return SKV_ERR_UNSUPPORTED;
+    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits + select_sets / 8,
+                  scale, resident_sets, early_of, early_staging, early_chunks, early_max};
+    return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
+                                     v_cache, nullptr, host_block_stride, cache_stride_h,
+                                     (long long)sparse_start * head_dim, (hipStream_t)stream, &al));
+}
+
 int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
@@ -361,18 +437,29 @@ int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const void* cos_sin
                               int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, int resident_sets, float scale, skv_stream_t stream) {
-    if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache || !q ||
-        !attn_workspace)
-        return SKV_ERR_ARG;
-    if ((rope_mode != 1 && rope_mode != 2) || heads < 1 || q_heads % heads || chunk_size != 8) return SKV_ERR_ARG;
-    if (select_sets % 8) return SKV_ERR_UNSUPPORTED;
-    AttnLaunch al{q, attn_workspace, kv_len_dev, kv_len, kv_rows, q_heads / heads, attn_splits, attn_splits + select_sets / 8,
-                  scale, resident_sets};
-    return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
-                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
-                                     cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
-                                     v_cache, nullptr, host_block_stride, cache_stride_h,
-                                     (long long)sparse_start * head_dim, (hipStream_t)stream, &al));
+    return fetch_kv_attn_inplace_impl(U, SV, cos_sin, miss_ids, dst_slots, cnts, k_cache, v_host, v_cache, q, attn_workspace,
+                                      kv_len_dev, kv_len, kv_rows, batch_size, heads, q_heads, seq_len, head_dim, rank,
+                                      select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h, cache_stride_s,
+                                      sparse_start, rope_mode, host_block_stride, attn_splits, resident_sets, scale, stream,
+                                      nullptr, nullptr, 0, 0);
+}
+
+int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                                    const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
+                                    void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,
+                                    int kv_rows, int batch_size, int heads, int q_heads, int seq_len, int head_dim, int rank,
+                                    int select_sets, int chunk_size, long long cos_sin_stride, long long cache_stride_b,
+                                    long long cache_stride_h, long long cache_stride_s, int sparse_start, int rope_mode,
+                                    long long host_block_stride, int attn_splits, int resident_sets, float scale,
+                                    const void* early_state, int n_landmarks, int n_chunks, int early_max,
+                                    skv_stream_t stream) {
+    if (!early_state || heads < 1 || q_heads % heads || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, q_heads / heads, n_landmarks, n_chunks, early_max);
+    return fetch_kv_attn_inplace_impl(U, SV, cos_sin, miss_ids, dst_slots, cnts, k_cache, v_host, v_cache, q, attn_workspace,
+                                      kv_len_dev, kv_len, kv_rows, batch_size, heads, q_heads, seq_len, head_dim, rank,
+                                      select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h, cache_stride_s,
+                                      sparse_start, rope_mode, host_block_stride, attn_splits, resident_sets, scale, stream,
+                                      es.early_of, es.staging, n_chunks, early_max);
 }
 
 int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,

@@ -1,0 +1,153 @@
+// Speculative early V fetch (round 3; VERDICT r2 item 4 "shorten the 22 us in front of the link") - device roles.
+//
+// The V rows of a step's miss chunks can only be requested over PCIe once the top-k has named them, i.e. behind scan +
+// normalise + top-k (8 + 5 + 9 us at the headline shape, 10 + 7 + 12 at GLM-4 200K), and the link is what bounds the fetch
+// launch (1.4 MB at 55 GB/s = 26 us).  Which chunks will miss is predictable right after the SCAN: the k-th largest score
+// moves very little from step to step, so "this slot's logit reaches last step's threshold, and its chunk is not resident"
+// names 98 % of the step's misses with 8 % extra (tools/spec_fetch_sim.py on the bench workload).  Everything rides in
+// launches that exist anyway - a forked stream was measured first and costs more than it hides (two cross-stream edges per
+// layer in the captured graph: 216 -> 178 tokens/s even when a single chunk is pulled; and the normalise launch runs 5 -> 14
+// us while host reads are in flight beside it; profiles/r03_early_fetch.txt):
+//   * scan launch: flags the landmark slots whose logit reaches dthr[b][g] (per query head: max_g + ln(k-th value / inv_g)
+//     of the PREVIOUS step, written by that step's top-k launch), <= SKV_EARLY_K per 256-slot tile;
+//   * normalise launch, ONE extra workgroup per (batch, KV head) - skv_early_prep_role: compacts the flagged slots, looks
+//     their chunk ids up, drops the resident ones (LDS bitmap of the resident ids), takes the first E, publishes them
+//     (early_ids, early_of[chunk] = staging index).  No host access yet: the normalise launch is latency-bound and slows
+//     down 3x beside PCIe reads;
+//   * top-k launch, ONE extra workgroup per (batch, KV head) - skv_early_pull_role: pulls the published chunks from the
+//     pinned host table into an HBM staging buffer while the top-k (LDS-bound, one CU per head) runs;
+//   * fetch launch (skv_rebuild.hip): a miss chunk with early_of[chunk] >= 0 is read from staging instead of the host.
+// Nothing here can change a result: staged bytes are the host table's bytes, a wrong prediction costs PCIe bytes only
+// (bounded by E), a missing one is fetched as before.
+#pragma once
+#include "skv_common.h"
+#include "skv_launch.h"
+
+#define EF_MAX_E 128
+#define EF_MAX_CAND 4096                 // flagged slots examined per head and step (more are dropped)
+
+// inclusive block scan of one int per thread; s_w: THREADS / 64 ints.  Two barriers.
+template <int THREADS>
+__device__ __forceinline__ int ef_block_scan_incl(int v, int* s_w, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w)
+        if (w < wave) add += s_w[w];
+    __syncthreads();
+    return x + add;
+}
+
+static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
+    return ((size_t)(n_chunks + 31) / 32 + EF_MAX_CAND + 64) * sizeof(int);
+}
+
+// One workgroup of THREADS threads for (batch, head) b.  T <= THREADS tiles, R <= THREADS resident slots.
+template <int THREADS>
+__device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem) {
+    constexpr int CPT = EF_MAX_CAND / THREADS;
+    const int n_chunks = eh.n_chunks, E = eh.E, T = eh.T, N = eh.N, R = eh.R;
+    const int words = (n_chunks + 31) / 32;
+    int* const s_bits = smem;                              // [words] resident chunk ids
+    int* const s_list = s_bits + words;                    // [EF_MAX_CAND] flagged slots, tile order
+    int* const s_w = s_list + EF_MAX_CAND;                 // [<= 16] scan scratch, [32..33] totals
+    // ---- requests whose addresses are known: this thread's tile (count + SKV_EARLY_K slots), this thread's resident id,
+    // and last step's list, whose early_of entries go back to -1 first (the stores are acknowledged - s_waitcnt below, behind
+    // the gathers every thread waits for anyway - before any thread writes a new entry: two barriers lie in between)
+    const int prev_n = min(eh.early_cnt[b], E);
+    const int prev_id = tid < E ? eh.early_ids[(size_t)b * E + tid] : -1;
+    int cnt = 0;
+    u32x4 fs[SKV_EARLY_K / 4];
+    if (tid < T) {
+        cnt = eh.flag_cnt[(size_t)b * T + tid];
+#pragma unroll
+        for (int k = 0; k < SKV_EARLY_K / 4; ++k)
+            fs[k] = reinterpret_cast<const u32x4*>(eh.flag_slot + ((size_t)b * T + tid) * SKV_EARLY_K)[k];
+    }
+    const long long my_res = tid < R ? eh.resident[(size_t)b * R + tid] : -1ll;
+    for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
+    if (tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
+    __syncthreads();
+    if (my_res >= 0 && my_res < n_chunks) atomicOr(&s_bits[my_res >> 5], 1 << (my_res & 31));
+    cnt = min(max(cnt, 0), SKV_EARLY_K);
+    const int incl = ef_block_scan_incl<THREADS>(cnt, s_w, tid);   // (the bitmap is complete behind its barriers)
+    if (tid == THREADS - 1) s_w[32] = incl;                // total = inclusive value of the last thread
+    {
+        const int off = incl - cnt;
+#pragma unroll
+        for (int k = 0; k < SKV_EARLY_K; ++k)
+            if (k < cnt && off + k < EF_MAX_CAND) s_list[off + k] = (int)fs[k / 4][k % 4];
+    }
+    __syncthreads();
+    const int total = min(s_w[32], EF_MAX_CAND);
+    // ---- slot -> chunk id (one more round trip), residency, ordered compaction of the first E non-resident ones
+    // (candidate i = c * THREADS + tid: a thread's candidates are spread over the list, and every gather is issued
+    // unconditionally - a load under `if` would be followed by a wait for its round trip, 16 of them in a row)
+    long long id[CPT];
+    int nkeep = 0;
+    unsigned keepm = 0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int i = c * THREADS + tid;
+        const int slot = i < total ? s_list[i] : 0;
+        id[c] = eh.lm_idx[(size_t)b * N + min(max(slot, 0), N - 1)];
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const bool real = c * THREADS + tid < total;
+        if (real && id[c] >= 0 && id[c] < n_chunks && !((s_bits[id[c] >> 5] >> (id[c] & 31)) & 1)) {
+            keepm |= 1u << c;
+            ++nkeep;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clears above are in L2)
+    const int kincl = ef_block_scan_incl<THREADS>(nkeep, s_w, tid);
+    if (tid == THREADS - 1) eh.early_cnt[b] = min(kincl, E);
+    int pos = kincl - nkeep;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        if ((keepm >> c) & 1u) {
+            if (pos < E) {
+                eh.early_ids[(size_t)b * E + pos] = (int)id[c];
+                eh.early_of[(size_t)b * n_chunks + id[c]] = (short)pos;
+            }
+            ++pos;
+        }
+    }
+}
+
+// One workgroup of THREADS threads for (batch, head) b: pulls the chunks the prep role published.  s_sel: EF_MAX_E ints.
+template <int THREADS>
+__device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b, int tid, int* s_sel) {
+    const int E = eh.E;
+    const int n_sel = min(eh.early_cnt[b], E);
+    if (tid < EF_MAX_E) s_sel[tid] = tid < E ? eh.early_ids[(size_t)b * E + tid] : 0;
+    __syncthreads();
+    // chunk e = 128 units of 16 B; 8 requests per thread in flight (unconditional loads through a selected pointer: a load
+    // under `if` would be followed by a wait for the PCIe round trip)
+    const u32x4* const hb = reinterpret_cast<const u32x4*>(eh.v_host) + (long long)b * eh.v_host_stride_u128;
+    u32x4* const sb = reinterpret_cast<u32x4*>(eh.staging) + (size_t)b * E * 128;
+    for (int r0 = 0; r0 * THREADS < n_sel * 128; r0 += 8) {
+        u32x4 v[8];
+        int dst[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = (r0 + k) * THREADS + tid, e = idx >> 7, u = idx & 127;
+            const bool on = e < n_sel;
+            dst[k] = on ? idx : -1;
+            const u32x4* src = on ? hb + (long long)s_sel[e] * 128 + u : reinterpret_cast<const u32x4*>(sb) + u;
+            v[k] = *src;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (dst[k] >= 0) sb[dst[k]] = v[k];
+    }
+}

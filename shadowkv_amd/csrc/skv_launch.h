@@ -1,5 +1,7 @@
 // Host-side launch descriptors shared between the API layer (skv_api.hip) and the kernel files.
 #pragma once
+#include <stdint.h>
+#include <stddef.h>
 
 // attention role of the fused in-place fetch launch (skv_rebuild.hip)
 struct AttnLaunch {
@@ -11,4 +13,74 @@ struct AttnLaunch {
     int G, splits, rec_splits;
     float scale;
     int resident_sets;       // slots of the sparse region (>= select_sets; the generated rows sit behind resident_sets * 8 rows)
+    // speculative early V fetch (skv_early.hip), all null / 0 = off: a miss chunk c with early_of[bh][c] = e >= 0 has its
+    // 2 KiB in early_staging[bh][e] already - the landing waves read it from there instead of the host table
+    const short* early_of;   // [bs*heads][early_chunks]
+    const void* early_staging;
+    int early_chunks, early_max;
 };
+
+// Hooks of the speculative early V fetch in the selection launches (skv_select.hip, roles in skv_early.h); dthr_in null = off.
+//   scan:      a landmark slot whose logit reaches dthr_in[b][g] for some query head g is FLAGGED (it would have made the
+//              previous step's top-k): per tile the first SKV_EARLY_K flagged slots go to flag_slot, their number to flag_cnt.
+//              Prediction only - the selection itself never reads it.
+//   normalise: workgroup 0 of a head leaves the rows' finals (max, 1 / sum) in finals[b][g][2]; one extra workgroup per head
+//              turns the flags into the list of chunks to pull (skv_early_prep_role).
+//   top-k:     dthr_out[b][g] for the NEXT step = max_g + ln(k-th value / inv_g) + margin  (P >= k-th value <=> D >= this);
+//              one extra workgroup per head pulls the listed chunks into the staging buffer (skv_early_pull_role).
+struct EarlyHooks {
+    const float* dthr_in;
+    int* flag_cnt;
+    int* flag_slot;
+    float* finals;
+    float* dthr_out;
+    int G;
+    float margin;
+    const int64_t* lm_idx;      // [B][N] slot -> chunk id
+    const int64_t* resident;    // [B][R] resident chunk ids
+    int* early_cnt;
+    int* early_ids;
+    short* early_of;
+    const void* v_host;
+    long long v_host_stride_u128;
+    void* staging;
+    int T, N, R, n_chunks, E;
+};
+
+// Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.
+//   dthr      [B][G]    f32   logit threshold of query head g for the NEXT step's scan: a landmark slot is flagged when some
+//                              head's logit reaches it (= the slot would have made the previous step's top-k); +inf: none
+//   finals    [B][G][2] f32   (max, 1 / sum) of this step's softmax rows, left by the normalise launch for the top-k launch
+//   flag_cnt  [B][T]    i32   flagged slots of tile t (<= SKV_EARLY_K kept), flag_slot [B][T][SKV_EARLY_K] the slots
+//   early_cnt [B]       i32   chunks the early launch pulled this step, early_ids [B][E] their chunk ids
+//   early_of  [B][chunks] i16 staging index of a chunk pulled early this step, -1 otherwise
+//   staging   [B][E][2 KiB]   the pulled V chunks
+#define SKV_EARLY_K 16
+struct EarlyState {
+    float* dthr;
+    float* finals;
+    int* flag_cnt;
+    int* flag_slot;
+    int* early_cnt;
+    int* early_ids;
+    short* early_of;
+    void* staging;
+    size_t total;
+};
+static inline size_t skv_early_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline EarlyState skv_carve_early(void* base, int B, int G, int n_landmarks, int n_chunks, int E) {
+    const size_t T = (size_t)(n_landmarks + 255) / 256;
+    unsigned char* p = (unsigned char*)base;
+    size_t off = 0;
+    EarlyState e;
+    e.dthr = (float*)(p + off);      off += skv_early_align((size_t)B * G * 4);
+    e.finals = (float*)(p + off);    off += skv_early_align((size_t)B * G * 8);
+    e.flag_cnt = (int*)(p + off);    off += skv_early_align((size_t)B * T * 4);
+    e.flag_slot = (int*)(p + off);   off += skv_early_align((size_t)B * T * SKV_EARLY_K * 4);
+    e.early_cnt = (int*)(p + off);   off += skv_early_align((size_t)B * 4);
+    e.early_ids = (int*)(p + off);   off += skv_early_align((size_t)B * E * 4);
+    e.early_of = (short*)(p + off);  off += skv_early_align((size_t)B * n_chunks * 2);
+    e.staging = p + off;             off += skv_early_align((size_t)B * E * 2048);
+    e.total = off;
+    return e;
+}

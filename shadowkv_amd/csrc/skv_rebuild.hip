@@ -68,6 +68,9 @@ struct AttnRole {
     int kv_len_host, kv_rows, splits, rec_splits;
     int resident_rows;        // rows of the sparse region (resident slots x 8): the generated rows sit behind it
     float scale;
+    const short* early_of;    // speculative early V fetch (skv_early.hip; null = off): staging index per chunk id
+    const u32x4* early_staging;
+    int early_chunks, early_max;
 };
 
 
@@ -348,6 +351,18 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
                 loff[k] = hit_offsets[(size_t)bh * S + j];        // miss id (source chunk) and destination slot of the
                 lslot[k] = dst_slots[(size_t)bh * S + j];         // thread's four chunks; stale for j < cnt, unused then
             }
+            // chunks the early launch has staged already (a second, dependent lookup - it returns well inside the wait for
+            // barrier (1), which stands behind TWO dependent round trips of the rebuild waves)
+            int lsrc[4] = {-1, -1, -1, -1};
+            if (ar.early_of != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = jb + 2 * k + rsub;
+                    const int c = min(max(loff[k], 0), ar.early_chunks - 1);
+                    const int e = ar.early_of[(size_t)bh * ar.early_chunks + c];
+                    lsrc[k] = (j >= cnt && j < S && loff[k] == c && e < ar.early_max) ? e : -1;
+                }
+            }
             u32x4 qreg = {0u, 0u, 0u, 0u};
             if (vt < AG * 16) qreg = reinterpret_cast<const u32x4*>(ar.q + (size_t)bh * AG * AT_D)[vt];
             if (vt < AG * 16) *reinterpret_cast<u32x4*>(sOut + RB_ROWS * RB_OUT_PITCH + vt * 16) = qreg;
@@ -365,8 +380,9 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
                 lact[k] = j >= cnt && j < S;
                 // unconditional load through a selected pointer: a load under `if` makes hipcc wait vmcnt(0) right behind
                 // it, i.e. one PCIe round trip per chunk; dead chunks read a (valid, unused) row of the device cache instead
-                const u32x4* src = lact[k] ? v_host + ((long long)bh * v_host_stride_u128 + (long long)loff[k] * 128 + unit)
-                                           : v_buf + ((long long)bh * v_stride_u128 + v_off_u128 + unit);
+                const u32x4* src = !lact[k] ? v_buf + ((long long)bh * v_stride_u128 + v_off_u128 + unit)
+                                   : lsrc[k] >= 0 ? ar.early_staging + (((long long)bh * ar.early_max + lsrc[k]) * 128 + unit)
+                                                  : v_host + ((long long)bh * v_host_stride_u128 + (long long)loff[k] * 128 + unit);
                 lv[k] = *src;
             }
             asm volatile("" ::: "memory");
@@ -586,8 +602,10 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
             (long long)attn->kv_rows * RB_D > out_stride_h ||
             (!attn->kv_len_dev && (attn->kv_len_host < 1 || attn->kv_len_host > attn->kv_rows)))
             return SKV_ERR_ARG;
+        if (attn->early_of && (!attn->early_staging || attn->early_chunks < 1 || attn->early_max < 1)) return SKV_ERR_ARG;
         ar = AttnRole{(const bf16_t*)attn->q, (float*)attn->ws, attn->kv_len_dev, attn->kv_len_host, attn->kv_rows,
-                      attn->splits, attn->rec_splits, attn->resident_sets * C, attn->scale};
+                      attn->splits, attn->rec_splits, attn->resident_sets * C, attn->scale, attn->early_of,
+                      (const u32x4*)attn->early_staging, attn->early_chunks, attn->early_max};
         attn_g = attn->G;
         // fused tile: SV staging (later: the tile attention's V image / weights) | K tile | q
         const size_t part = (size_t)AT_GROUPS * attn_g * (AT_D + 2) * sizeof(float);

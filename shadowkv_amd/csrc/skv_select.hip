@@ -15,6 +15,8 @@
 // layer at the headline config) and is HBM-bound; everything after it touches <= 1.3 MB.
 #include "skv_common.h"
 #include "skv_select_front.h"
+#include "skv_launch.h"
+#include "skv_early.h"
 
 #define SKV_TILE 256  // columns per partial tile == the reference's ThreadblockShape::kN
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
     bf16_t* __restrict__ D,          // [B][G][N]
     float* __restrict__ part_max,    // [B][T][G]
     float* __restrict__ part_sum,    // [B][T][G]
-    int N, int T, float alpha) {
+    int N, int T, float alpha, EarlyHooks eh) {
     constexpr int ITERS = 64 / WAVES;               // 4-row wave-instructions per wave
     constexpr int GH = G > 8 ? 4 : G;               // query heads per pass
     constexpr int PASSES = G / GH;
@@ -123,6 +125,8 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         }
     }
 
+    const bool flag_wave = ABL == 0 && eh.dthr_in != nullptr && wave == (G < WAVES ? G : 0);
+    __shared__ float s_dth[G];
     const int row0 = t * SKV_TILE + wave * (4 * ITERS) + rsel;
     u32x4 x[ITERS];
     auto request = [&](int i) __attribute__((always_inline)) {
@@ -132,6 +136,9 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
     };
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) request(i);
+    // early fetch: the flag wave's thresholds travel behind its row requests into LDS (read behind the barrier; no register
+    // is held across the loop: the G = 4 kernel sits exactly at its 64-VGPR budget)
+    if (flag_wave && lane < G) s_dth[lane] = eh.dthr_in[(size_t)b * G + lane];
     if (ABL == 1) {   // memory stream only: fold the loaded words so the loads stay, skip all arithmetic
         uint32_t f = 0;
 #pragma unroll
@@ -181,6 +188,29 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         return;
     }
 
+    // early-fetch flags (off: eh.dthr_in == nullptr): one wave that has no query head in the statistics below (or wave 0)
+    // compares its 4 columns' logits with the heads' thresholds and compacts the flagged slots of the tile
+    if (flag_wave) {
+        const int c0 = 4 * lane;
+        unsigned fl = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float th = s_dth[g];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t * SKV_TILE + c0 + k < N && bf2f(sD[g][c0 + k]) >= th) fl |= 1u << k;
+        }
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long bal = __ballot((fl >> k) & 1u);
+            const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (((fl >> k) & 1u) && pos < SKV_EARLY_K)
+                eh.flag_slot[((size_t)b * T + t) * SKV_EARLY_K + pos] = t * SKV_TILE + c0 + k;
+            base += __builtin_popcountll(bal);
+        }
+        if (lane == 0) eh.flag_cnt[(size_t)b * T + t] = min(base, SKV_EARLY_K);
+    }
     // per-tile statistics: wave w owns query head g = w (+ k*waves) and all 256 columns of the tile, 4 consecutive
     // columns per lane, so max, integer exp-sum and the logit store need no cross-wave step and no further barrier
     // (ablation, tools/score_probe.hip: the previous column-per-thread tail cost 3.5 of 11.5 us).
@@ -279,9 +309,15 @@ template <int G>
 __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
     const bf16_t* __restrict__ D, const float* __restrict__ part_max, const float* __restrict__ part_sum,
     bf16_t* __restrict__ P /* nullable, [B][G][N] */, bf16_t* __restrict__ score /* [B][score_stride] */, int N, int T,
-    int score_stride, int tiles_per_block) {
+    int score_stride, int tiles_per_block, EarlyHooks eh, int prep_block /* blockIdx.x of the early-fetch role, -1: none */) {
     const int b = blockIdx.y, t0 = blockIdx.x * tiles_per_block;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x == prep_block) {                 // early fetch: flags -> list of chunks to pull (skv_early.h)
+        extern __shared__ __attribute__((aligned(16))) int smem_prep[];
+        skv_early_prep_role<256>(eh, b, tid, smem_prep);
+        return;
+    }
+    float* const finals_out = eh.finals;
     __shared__ float s_m[G], s_inv[G];
     // the first tile's G logits do not depend on the statistics: request them first (one memory round trip, not two)
     bf16_t dreg[G];
@@ -341,6 +377,10 @@ __global__ __launch_bounds__(256) void skv_normalize_groupmax_kernel(
         }
     }
     __syncthreads();
+    if (finals_out != nullptr && blockIdx.x == 0 && tid < G) {
+        finals_out[((size_t)b * G + tid) * 2] = s_m[tid];
+        finals_out[((size_t)b * G + tid) * 2 + 1] = s_inv[tid];
+    }
     for (int tt = 0; tt < tiles_per_block; ++tt) {
         const int col = (t0 + tt) * SKV_TILE + tid;
         if (col >= N) return;
@@ -721,7 +761,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     // [B][R], the S - cnt misses replace the least recently selected of the R - cnt slots that were not selected now
     // (age = steps since the slot's chunk was last selected, saturating at 62; 63 = empty slot; ties -> lowest slot).
     // R == S: every slot that was not selected is replaced, slot_age is not touched (may be null).
-    int R, int RP /* pow2 >= R */, int32_t* __restrict__ slot_age /* [B][R] */) {
+    int R, int RP /* pow2 >= R */, int32_t* __restrict__ slot_age /* [B][R] */, EarlyHooks eh) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_cur = s_hist + T2_BINS * T2_COPIES;        // [SP]   selected landmark slot per output position
@@ -734,7 +774,12 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_rank = s_miss + SP;                        // [SP]
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= gridDim.x / 2 && eh.staging != nullptr) {   // early fetch: the second half of the grid pulls (skv_early.h)
+        skv_early_pull_role<T2_THREADS>(eh, blockIdx.x - gridDim.x / 2, tid, smem);
+        return;
+    }
+    const int b = blockIdx.x;
     TOPK_STAMP(0);
     constexpr int NW = 4 * SEGV;                      // 32-bit words (two keys each) per thread
     constexpr int NG = (NW + 15) / 16;                // mask registers: 16 words (32 keys) each
@@ -791,6 +836,11 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         }
         int thr, need_eq;
         t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - N, S, tid, s_hist, s_w, s_out, thr, need_eq, insert_resident);
+        if (eh.dthr_out != nullptr && tid < eh.G) {       // next step's flag thresholds (early fetch; prediction only)
+            const float kth = __uint_as_float((uint32_t)thr << 16);
+            const float mx = eh.finals[((size_t)b * eh.G + tid) * 2], inv = eh.finals[((size_t)b * eh.G + tid) * 2 + 1];
+            eh.dthr_out[(size_t)b * eh.G + tid] = (kth > 0.f && inv > 0.f) ? mx + __logf(kth / inv) + eh.margin : INFINITY;
+        }
         // ---- flags of the thread's keys as bit masks: bit 2i + h of word-group g <=> key (i, h) >= thr (mge) / > thr (mgt).
         // keys are < 0x8000, so key + (0x8000 - thr) has bit 15 set iff key >= thr, and the two halves of a word never carry
         // into each other
@@ -1055,21 +1105,23 @@ static inline int next_pow2(int v) {
 
 template <int G>
 static int launch_score_g(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int N, int T,
-                          float alpha, hipStream_t st) {
+                          float alpha, hipStream_t st, const EarlyHooks& eh) {
     hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(64 * (G == 8 ? 8 : SKV_SCORE_WAVES)), 0, st, (const bf16_t*)q,
-                       (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha);
+                       (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha, eh);
     return SKV_OK;
 }
 
 int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
-                     float alpha, hipStream_t st) {
+                     float alpha, hipStream_t st, const EarlyHooks* hooks) {
     const int T = (N + SKV_TILE - 1) / SKV_TILE;
+    EarlyHooks eh{};
+    if (hooks) eh = *hooks;
     switch (G) {
-        case 1: return launch_score_g<1>(q, lm, D, pmax, psum, B, N, T, alpha, st);
-        case 2: return launch_score_g<2>(q, lm, D, pmax, psum, B, N, T, alpha, st);
-        case 4: return launch_score_g<4>(q, lm, D, pmax, psum, B, N, T, alpha, st);
-        case 8: return launch_score_g<8>(q, lm, D, pmax, psum, B, N, T, alpha, st);
-        case 16: return launch_score_g<16>(q, lm, D, pmax, psum, B, N, T, alpha, st);
+        case 1: return launch_score_g<1>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
+        case 2: return launch_score_g<2>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
+        case 4: return launch_score_g<4>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
+        case 8: return launch_score_g<8>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
+        case 16: return launch_score_g<16>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
         default: return SKV_ERR_UNSUPPORTED;
     }
 }
@@ -1084,13 +1136,21 @@ int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void
 }
 
 int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,
-                                  int score_stride, int B, int G, int N, hipStream_t st) {
+                                  int score_stride, int B, int G, int N, hipStream_t st, const EarlyHooks* hooks) {
+    EarlyHooks eh{};
+    if (hooks) eh = *hooks;
     const int T = (N + SKV_TILE - 1) / SKV_TILE;
     const int tpb = T >= 1024 ? 8 : T >= 256 ? 4 : 1;   // per-workgroup finals cost O(T): amortise them for long contexts
     const int gx = (T + tpb - 1) / tpb;
+    // early fetch: one more workgroup per head (the list of chunks to pull); it is the only one that uses dynamic LDS
+    const bool prep = eh.dthr_in != nullptr;
+    if (prep && (T > 256 || eh.R > 256)) return SKV_ERR_UNSUPPORTED;
+    const size_t smem = prep ? skv_early_prep_lds_bytes(eh.n_chunks) : 0;
+    if (smem > 60 * 1024) return SKV_ERR_UNSUPPORTED;
+    const int prep_block = prep ? gx : -1;
 #define SKV_NG(GG)                                                                                              \
-    hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(gx, B), dim3(256), 0, st, (const bf16_t*)D, pmax, \
-                       psum, (bf16_t*)P, (bf16_t*)score, N, T, score_stride, tpb)
+    hipLaunchKernelGGL((skv_normalize_groupmax_kernel<GG>), dim3(gx + (prep ? 1 : 0), B), dim3(256), smem, st, (const bf16_t*)D, pmax, \
+                       psum, (bf16_t*)P, (bf16_t*)score, N, T, score_stride, tpb, eh, prep_block)
     switch (G) {
         case 1: SKV_NG(1); break;
         case 2: SKV_NG(2); break;
@@ -1106,21 +1166,26 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
 template <int SEGV>
 static int launch_topk2(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
                         int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
-                        int SP, int R, int RP, int32_t* slot_age, hipStream_t st) {
+                        int SP, int R, int RP, int32_t* slot_age, hipStream_t st, const EarlyHooks& eh) {
     const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 5 + RP + H * 2 + 80 + 16) * sizeof(int);
     static size_t attr_bytes[64] = {};
     if (skv_ensure_max_lds((const void*)skv_topk2_kernel<SEGV>, (size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96) * sizeof(int),
                            attr_bytes) != SKV_OK)
         return SKV_ERR_LAUNCH;
-    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
-                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age);
+    const bool pull = eh.staging != nullptr && eh.dthr_in != nullptr;
+    EarlyHooks ek = eh;
+    if (!pull) ek.staging = nullptr;
+    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(pull ? 2 * B : B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
+                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age, ek);
     return SKV_OK;
 }
 
 int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
-                            int B, int N, int S, int R, int32_t* slot_age, hipStream_t st) {
+                            int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks) {
     if (S < 1 || S > SKV_SEL_THREADS || R < S || R > T2_THREADS) return SKV_ERR_UNSUPPORTED;
+    EarlyHooks eh{};
+    if (hooks) eh = *hooks;
     if (score != nullptr && (N < S || score_stride < N || (score_stride % 8))) return SKV_ERR_ARG;
     if (R > S && (!dst_slots || !slot_age)) return SKV_ERR_ARG;      // a larger resident set exists in the in-place layout only
     const int SP = next_pow2(S), RP = next_pow2(R);
@@ -1128,13 +1193,14 @@ int skv_launch_topk_resident(const void* score, int score_stride, const int64_t*
 #ifndef SKV_TOPK_V1
     {   // second-generation kernel: scores in registers, <= 16 vectors (128 scores) per thread
         const int per_thread = score ? (score_stride / 8 + T2_THREADS - 1) / T2_THREADS : 1;
-        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
-        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
-        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
-        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
-        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st);
+        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
+        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
+        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
+        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
+        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
     }
 #endif
+    if (eh.dthr_in != nullptr) return SKV_ERR_UNSUPPORTED;   // early fetch: the pull role rides in the second-generation kernel
     if (R != S) return SKV_ERR_UNSUPPORTED;   // rows longer than 131,072 scores: first-generation kernel, R == S only
     const size_t base = (size_t)(SP * 4 + H * 2 + 256 + 32 + 8 + 256 * 32) * sizeof(int);
     const size_t with_score = base + (size_t)score_stride * sizeof(bf16_t);
@@ -1159,5 +1225,5 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st) {
     return skv_launch_topk_resident(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, S,
-                                    nullptr, st);
+                                    nullptr, st, nullptr);
 }

@@ -221,6 +221,7 @@ class ShadowKVCache_CPU:
         self.output = torch.zeros(bs, kv, self.sparse_budget, D, device=self.device, dtype=dtype)
         self._staged_layer = -1
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
+        self._early = None               # speculative early V fetch (enable_early_fetch): per-layer states, side stream, events
         # measurement hook (bench.py): a list -> every fetch launch of the in-place path is bracketed by two events on the
         # current stream and (start, end, layer) is appended; None (default): nothing is recorded
         self.fetch_events = None
@@ -551,6 +552,67 @@ class ShadowKVCache_CPU:
                 and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 64
                 and self.block_num <= 8)
 
+    def early_fetch_supported(self):
+        """Shapes the early-fetch roles are built for (csrc/skv_early.h): <= 65,536 landmarks and <= 256 resident slots per
+        head, V table in pinned host memory."""
+        return (self.k_landmark is not None and self.k_landmark.shape[-2] <= 65536 and self.resident_sets <= 256
+                and self.v_cache_cpu is not None and self.v_cache_cpu.is_pinned())
+
+    def enable_early_fetch(self, early_max=None, margin=0.0):
+        """Speculative early V fetch for select_fetch_attend_inplace (csrc/skv_early.hip): the scan launch flags the
+        landmark slots that would have made the PREVIOUS step's top-k, an extra workgroup of the normalise launch lists up
+        to `early_max` of their non-resident chunks per head, an extra workgroup of the top-k launch pulls those from the
+        pinned host table while the top-k runs, and the fetch launch reads them from HBM.  Same results bit for bit; a wrong guess costs PCIe bytes only.
+        early_max None: 20 chunks per head for G <= 4, 48 for G = 8 (what the link moves while the top-k runs at the
+        BASELINE shapes: 12 / 20 / 28 measured 214.8 / 217.3 / 217.6 tokens/s at config 1, 40 / 48 / 64 / 96 measured 183.6 /
+        185.4 / 183.2 / 174.0 at config 3); 0 / False switches it off again."""
+        if not early_max and early_max is not None:
+            self._early = None
+            return
+        if not self.early_fetch_supported():
+            raise RuntimeError("early fetch needs the prefilled state with the V table in pinned host memory, at most 65,536 "
+                               "landmarks and at most 256 resident slots per head")
+        L = lib()
+        E = int(early_max) if early_max else (20 if self.num_key_value_groups <= 4 else 48)
+        E = max(1, min(E, 128))
+        n_lm, n_chunks = self.k_landmark.shape[-2], self.v_cache_cpu.shape[-2]
+        nbytes = int(L.skv_early_state_bytes(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E))
+        states = torch.empty(self.num_layers, nbytes, dtype=torch.uint8, device=self.device)
+        st = current_stream_handle()
+        for l in range(self.num_layers):
+            check(L.skv_early_state_init(ptr(states[l]), self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, st),
+                  "early_state_init")
+        offs = (ctypes.c_longlong * 8)()
+        check(L.skv_early_state_offsets(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs), "early_state_offsets")
+        torch.cuda.synchronize(self.device)
+        self._early = dict(states=states, E=E, margin=float(margin), n_lm=n_lm, n_chunks=n_chunks, offsets=list(offs))
+
+    def early_fetch_counts(self, layer_idx):
+        """Chunks pulled early per (batch, head) in the last step of this layer (int32 [blocks]); diagnostic, synchronises."""
+        if self._early is None:
+            return None
+        e = self._early
+        o = e["offsets"]
+        return e["states"][layer_idx][o[4]:o[4] + 4 * self.block_num].view(torch.int32).cpu()
+
+    def early_fetch_stats(self, layer_idx):
+        """(chunks pulled early, of these selected - i.e. read from staging by the fetch launch -, misses) summed over the
+        heads, for the last step of this layer; diagnostic, synchronises."""
+        if self._early is None:
+            return None
+        e = self._early
+        o, E, B, S = e["offsets"], e["E"], self.block_num, self.select_sets
+        n = self.early_fetch_counts(layer_idx)
+        ids = e["states"][layer_idx][o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
+        cnts = self._cnts_layers[layer_idx].view(-1).cpu()
+        miss = self.offsets.view(B, S).cpu()
+        pulled = used = misses = 0
+        for b in range(B):
+            early = set(ids[b, :int(n[b])].tolist())
+            m = set(miss[b, int(cnts[b]):].tolist())
+            pulled += len(early); used += len(early & m); misses += len(m)
+        return pulled, used, misses
+
     def select_fetch_attend_inplace(self, layer_idx, query_states, cos_sin_cache, kv_len=0, kv_len_dev=None):
         """select_fetch_inplace + sparse attention of one layer with the attention over the already-resident rows
         (local, outliers, surviving chunks, generated tokens) running INSIDE the fetch launch, on the CUs the PCIe-bound
@@ -576,26 +638,36 @@ class ShadowKVCache_CPU:
         bs, Hq, D = q.shape[0], self.num_attention_heads, self.head_dim
         SA = self._overlap_splits()
         ws = tensor_op.attention_workspace(q.device, bs, Hq, SA + self.select_sets // 8)
-        check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
-                                          ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
-                                          ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
-                                          self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                                          self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128), st),
-              "select_chunks_inplace")
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
+        sel_args = (ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
+                    ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
+                    ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
+                    self.num_key_value_groups, lm.shape[-2], self.select_sets,
+                    self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
+        ea = self._early
+        if ea is not None:
+            check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
+                                                    ea["n_chunks"], ea["E"], ea["margin"], st),
+                  "select_chunks_inplace_early")
+        else:
+            check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
         scale = 1.0 / math.sqrt(D)
         ev0 = self._fetch_event()
-        check(L.skv_fetch_kv_attn_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
-                                          ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), ptr(q), ptr(ws),
-                                          ptr(kv_len_dev), int(kv_len), buf_rows, U.shape[0], self.num_key_value_heads, Hq,
-                                          U.shape[1], D, self.rank, self.select_sets, self.chunk_size,
-                                          cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
-                                          self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA,
-                                          self.resident_sets, scale, st),
-              "fetch_kv_attn_inplace")
+        fetch_args = (ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
+                      ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), ptr(q), ptr(ws),
+                      ptr(kv_len_dev), int(kv_len), buf_rows, U.shape[0], self.num_key_value_heads, Hq,
+                      U.shape[1], D, self.rank, self.select_sets, self.chunk_size,
+                      cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1), kbuf.stride(2),
+                      self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), SA,
+                      self.resident_sets, scale)
+        if ea is not None:
+            check(L.skv_fetch_kv_attn_inplace_early(*fetch_args, ptr(ea["states"][layer_idx]), ea["n_lm"], ea["n_chunks"],
+                                                    ea["E"], st), "fetch_kv_attn_inplace_early")
+        else:
+            check(L.skv_fetch_kv_attn_inplace(*fetch_args, st), "fetch_kv_attn_inplace")
         self._fetch_event(ev0, layer_idx)
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
         check(L.skv_attn_finish_inplace(ptr(ws), ptr(self.cnts), ptr(out), bs, Hq, self.num_key_value_heads,

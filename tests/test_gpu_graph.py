@@ -767,3 +767,30 @@ def test_sample_topk_keeps_every_logit_tied_with_the_kth_value(V):
     assert set(draws[:, 0].tolist()) == want0                                       # every tied logit drawn, nothing else
     kept1 = set(lead[:40].tolist()) | set(sorted(tied1.tolist())[:24])
     assert set(draws[:, 1].tolist()) == kept1
+
+
+def test_captured_step_with_early_fetch_replays_like_the_eager_step_without():
+    """Speculative early V fetch inside the captured step (extra workgroups of the normalise and top-k launches, staged chunks
+    consumed by the fetch launch): same tokens and cache bytes as the eager step without it, and the prediction fires."""
+    steps = 8
+    m1, llama = _make(layout="inplace", overlap=True)
+    m2, _ = _make(layout="inplace", overlap=True)
+    assert m2.kv_cache.can_overlap_attention()
+    m2.kv_cache.enable_early_fetch(early_max=8)
+    table = llama.make_walk_table(m1, steps, seed=3)
+    tok = torch.tensor([[17]], device=DEV)
+    t1, toks1 = tok.clone(), []
+    for i in range(steps):
+        t1 = m1.decode_step(t1, temperature=0.0, q_table=table[i])
+        toks1.append(int(t1))
+    dec = llama.GraphDecoder(m2, temperature=0.0, walk_table=table)
+    dec.token.copy_(tok)
+    warm = dec.capture(warmup=2)
+    toks2 = [int(dec.step()) for _ in range(steps - warm)]
+    torch.cuda.synchronize()
+    assert toks2 == toks1[warm:]
+    assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
+    assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
+    assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
+    pulled = sum(int(m2.kv_cache.early_fetch_counts(l).sum()) for l in range(m2.num_layers))
+    assert pulled > 0, "nothing was pulled early in the last captured step"

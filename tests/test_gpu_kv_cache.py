@@ -483,3 +483,49 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
     assert more_hits > 0, "the larger resident set never produced an extra hit"
     with pytest.raises(RuntimeError):
         big.get_retrieval_position_ids(0, q)
+
+
+@pytest.mark.parametrize("kv_heads,glm", [(8, False), (4, True)])
+def test_early_fetch_changes_no_bit(kv_heads, glm):
+    """Speculative early V fetch (csrc/skv_early.hip): flagged in the scan launch, pulled by a launch on a side stream beside
+    normalise + top-k, consumed from HBM staging by the fetch launch.  Against the same steps without it: attention output,
+    selection bookkeeping and both caches bit for bit; the V rows of the selected chunks equal the host table; and the
+    prediction does fire (chunks are pulled early once a previous step has left its thresholds)."""
+    ca, cs, g = _headline_cache(kv_heads, glm, L=16384, seed=23)
+    cb, _, _ = _headline_cache(kv_heads, glm, L=16384, seed=23)
+    ca.enable_early_fetch()
+    kv_len = ca.sparse_end + 2
+    q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
+    pulled, used = [], 0
+    for step in range(8):
+        if step == 5:
+            q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()    # new query: the prediction is poor
+        elif step == 3:
+            q = q.clone()                                                                  # same query: nothing to fetch
+        else:
+            q = (q.float() + 0.25 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+        before = ca.position_ids[0][0].clone()
+        oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        torch.cuda.synchronize()
+        n_early = ca.early_fetch_counts(0)
+        pulled.append(int(n_early.sum()))
+        assert int(n_early.max()) <= ca._early["E"]
+        assert torch.equal(ca.cnts, cb.cnts) and torch.equal(ca.offsets, cb.offsets)
+        assert torch.equal(ca.position_ids, cb.position_ids)
+        assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), (step, float((oa.float() - ob.float()).abs().max()))
+        assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16)), step
+        assert torch.equal(ca.k_cache_buffer.view(torch.int16), cb.k_cache_buffer.view(torch.int16)), step
+        # every resident chunk's V rows are the host table's rows
+        ids = ca.position_ids[0][0]                                                        # [kv, S] chunk ids per slot
+        vh = ca.v_cache_cpu[0][0]                                                          # [kv, chunks, 8 * 128] pinned host
+        for h in range(kv_heads):
+            want = vh[h][ids[h].cpu()].view(-1, 128)
+            got = ca.v_cache_buffer[0][0][h][ca.sparse_start:ca.sparse_start + ids.shape[1] * 8].cpu()
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (step, h)
+        # how many of this step's misses came from staging
+        new = (ca.position_ids[0][0] != before)
+        used += int(new.sum())
+    assert pulled[0] == 0, "no thresholds before the first step: nothing may be flagged"
+    assert max(pulled[1:]) > 0, f"the prediction never fired: {pulled}"
+    assert pulled[3] == 0 or pulled[3] <= pulled[2], pulled
