@@ -47,63 +47,60 @@ __device__ __forceinline__ int ef_block_scan_incl(int v, int* s_w, int tid) {
 }
 
 static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
-    return ((size_t)(n_chunks + 31) / 32 + EF_MAX_CAND + 64) * sizeof(int);
+    return ((size_t)(n_chunks + 31) / 32 + 64) * sizeof(int);
 }
 
-// One workgroup of THREADS threads for (batch, head) b.  T <= THREADS tiles, R <= THREADS resident slots.
+// One workgroup of THREADS threads for (batch, head) b.  R <= THREADS resident slots, T * SKV_EARLY_K <= EF_MAX_CAND.
+// Two dependent round trips (flag entries + resident ids + last step's list, then the slot -> chunk id gathers), one block
+// scan.  Candidate i = (tile i / K, entry i % K) is real when its entry index is below the tile's count; a thread's
+// candidates are i = c * THREADS + tid, and every load is issued unconditionally (a load under `if` would be followed by
+// a wait for its round trip - 16 of them in a row).
 template <int THREADS>
 __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem) {
     constexpr int CPT = EF_MAX_CAND / THREADS;
     const int n_chunks = eh.n_chunks, E = eh.E, T = eh.T, N = eh.N, R = eh.R;
     const int words = (n_chunks + 31) / 32;
     int* const s_bits = smem;                              // [words] resident chunk ids
-    int* const s_list = s_bits + words;                    // [EF_MAX_CAND] flagged slots, tile order
-    int* const s_w = s_list + EF_MAX_CAND;                 // [<= 16] scan scratch, [32..33] totals
-    // ---- requests whose addresses are known: this thread's tile (count + SKV_EARLY_K slots), this thread's resident id,
-    // and last step's list, whose early_of entries go back to -1 first (the stores are acknowledged - s_waitcnt below, behind
-    // the gathers every thread waits for anyway - before any thread writes a new entry: two barriers lie in between)
+    int* const s_w = s_bits + words;                       // [<= 16] scan scratch
+    const int total = min(T * SKV_EARLY_K, EF_MAX_CAND);
+    // ---- round trip 1.  Last step's early_of entries go back to -1 first (the stores are acknowledged - s_waitcnt below,
+    // behind the gathers every thread waits for anyway - before any thread writes a new entry: the scan's barriers lie between)
     const int prev_n = min(eh.early_cnt[b], E);
     const int prev_id = tid < E ? eh.early_ids[(size_t)b * E + tid] : -1;
-    int cnt = 0;
-    u32x4 fs[SKV_EARLY_K / 4];
-    if (tid < T) {
-        cnt = eh.flag_cnt[(size_t)b * T + tid];
+    const int rounds = (total + THREADS - 1) / THREADS;    // (uniform: 4 at the headline shape, 7 at GLM-4 200K)
+    int slot[CPT], tcnt[CPT];
 #pragma unroll
-        for (int k = 0; k < SKV_EARLY_K / 4; ++k)
-            fs[k] = reinterpret_cast<const u32x4*>(eh.flag_slot + ((size_t)b * T + tid) * SKV_EARLY_K)[k];
+    for (int c = 0; c < CPT; ++c) {
+        slot[c] = -1;
+        tcnt[c] = 0;
+        if (c < rounds) {
+            const int i = min(c * THREADS + tid, total - 1);
+            slot[c] = eh.flag_slot[(size_t)b * T * SKV_EARLY_K + i];
+            tcnt[c] = eh.flag_cnt[(size_t)b * T + i / SKV_EARLY_K];
+        }
     }
     const long long my_res = tid < R ? eh.resident[(size_t)b * R + tid] : -1ll;
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
     if (tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
     __syncthreads();
     if (my_res >= 0 && my_res < n_chunks) atomicOr(&s_bits[my_res >> 5], 1 << (my_res & 31));
-    cnt = min(max(cnt, 0), SKV_EARLY_K);
-    const int incl = ef_block_scan_incl<THREADS>(cnt, s_w, tid);   // (the bitmap is complete behind its barriers)
-    if (tid == THREADS - 1) s_w[32] = incl;                // total = inclusive value of the last thread
-    {
-        const int off = incl - cnt;
-#pragma unroll
-        for (int k = 0; k < SKV_EARLY_K; ++k)
-            if (k < cnt && off + k < EF_MAX_CAND) s_list[off + k] = (int)fs[k / 4][k % 4];
-    }
-    __syncthreads();
-    const int total = min(s_w[32], EF_MAX_CAND);
-    // ---- slot -> chunk id (one more round trip), residency, ordered compaction of the first E non-resident ones
-    // (candidate i = c * THREADS + tid: a thread's candidates are spread over the list, and every gather is issued
-    // unconditionally - a load under `if` would be followed by a wait for its round trip, 16 of them in a row)
+    // ---- round trip 2: slot -> chunk id
     long long id[CPT];
+    unsigned realm = 0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int i = c * THREADS + tid;
+        const bool real = i < total && (i % SKV_EARLY_K) < min(max(tcnt[c], 0), SKV_EARLY_K) && slot[c] >= 0 && slot[c] < N;
+        if (real) realm |= 1u << c;
+        id[c] = -1;
+        if (c < rounds) id[c] = eh.lm_idx[(size_t)b * N + (real ? slot[c] : 0)];
+    }
+    __syncthreads();                                       // the bitmap is complete
     int nkeep = 0;
     unsigned keepm = 0;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        const int i = c * THREADS + tid;
-        const int slot = i < total ? s_list[i] : 0;
-        id[c] = eh.lm_idx[(size_t)b * N + min(max(slot, 0), N - 1)];
-    }
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        const bool real = c * THREADS + tid < total;
-        if (real && id[c] >= 0 && id[c] < n_chunks && !((s_bits[id[c] >> 5] >> (id[c] & 31)) & 1)) {
+        if (((realm >> c) & 1u) && id[c] >= 0 && id[c] < n_chunks && !((s_bits[id[c] >> 5] >> (id[c] & 31)) & 1)) {
             keepm |= 1u << c;
             ++nkeep;
         }
