@@ -14,7 +14,7 @@
 //     their chunk ids up, drops the resident ones (LDS bitmap of the resident ids), takes the first E, publishes them
 //     (early_ids, early_of[chunk] = staging index).  No host access yet: the normalise launch is latency-bound and slows
 //     down 3x beside PCIe reads;
-//   * top-k launch, ONE extra workgroup per (batch, KV head) - skv_early_pull_role: pulls the published chunks from the
+//   * top-k launch, four extra workgroups per (batch, KV head) - skv_early_pull_role: pull the published chunks from the
 //     pinned host table into an HBM staging buffer while the top-k (LDS-bound, one CU per head) runs;
 //   * fetch launch (skv_rebuild.hip): a miss chunk with early_of[chunk] >= 0 is read from staging instead of the host.
 // Nothing here can change a result: staged bytes are the host table's bytes, a wrong prediction costs PCIe bytes only
@@ -121,9 +121,13 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     }
 }
 
-// One workgroup of THREADS threads for (batch, head) b: pulls the chunks the prep role published.  s_sel: EF_MAX_E ints.
+// Pull role: SKV_EARLY_PULL_WGS workgroups of THREADS threads per (batch, head) b, workgroup `part` takes the published
+// chunks e = part, part + PULL_WGS, ...  (How fast host memory can be read depends on how many CUs ask: one workgroup per
+// head - 4 CUs at GLM-4's shape - pulled 393 KB in 15 us = 26 GB/s and stretched the top-k launch from 12.7 to 18.5 us; with
+// four per head it ends with the top-k, 12.6 us.)  s_sel: EF_MAX_E ints.
+#define SKV_EARLY_PULL_WGS 4
 template <int THREADS>
-__device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b, int tid, int* s_sel) {
+__device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* s_sel) {
     const int E = eh.E;
     const int n_sel = min(eh.early_cnt[b], E);
     if (tid < EF_MAX_E) s_sel[tid] = tid < E ? eh.early_ids[(size_t)b * E + tid] : 0;
@@ -132,14 +136,15 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
     // under `if` would be followed by a wait for the PCIe round trip)
     const u32x4* const hb = reinterpret_cast<const u32x4*>(eh.v_host) + (long long)b * eh.v_host_stride_u128;
     u32x4* const sb = reinterpret_cast<u32x4*>(eh.staging) + (size_t)b * E * 128;
-    for (int r0 = 0; r0 * THREADS < n_sel * 128; r0 += 8) {
+    const int mine = (n_sel - part + SKV_EARLY_PULL_WGS - 1) / SKV_EARLY_PULL_WGS;      // chunks of this workgroup
+    for (int r0 = 0; r0 * THREADS < mine * 128; r0 += 8) {
         u32x4 v[8];
         int dst[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = (r0 + k) * THREADS + tid, e = idx >> 7, u = idx & 127;
+            const int idx = (r0 + k) * THREADS + tid, e = (idx >> 7) * SKV_EARLY_PULL_WGS + part, u = idx & 127;
             const bool on = e < n_sel;
-            dst[k] = on ? idx : -1;
+            dst[k] = on ? e * 128 + u : -1;
             const u32x4* src = on ? hb + (long long)s_sel[e] * 128 + u : reinterpret_cast<const u32x4*>(sb) + u;
             v[k] = *src;
         }

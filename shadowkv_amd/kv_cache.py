@@ -563,9 +563,9 @@ class ShadowKVCache_CPU:
         landmark slots that would have made the PREVIOUS step's top-k, an extra workgroup of the normalise launch lists up
         to `early_max` of their non-resident chunks per head, an extra workgroup of the top-k launch pulls those from the
         pinned host table while the top-k runs, and the fetch launch reads them from HBM.  Same results bit for bit; a wrong guess costs PCIe bytes only.
-        early_max None: 20 chunks per head for G <= 4, 48 for G = 8 (what the link moves while the top-k runs at the
-        BASELINE shapes: 12 / 20 / 28 measured 214.8 / 217.3 / 217.6 tokens/s at config 1, 40 / 48 / 64 / 96 measured 183.6 /
-        185.4 / 183.2 / 174.0 at config 3); 0 / False switches it off again."""
+        early_max None: 28 chunks per head for G <= 4, 64 for G = 8 (what the link moves while the top-k runs at the
+        BASELINE shapes: 20 / 24 / 28 / 36 measured 220.0 / 220.5 / 221.3 / 220.6 tokens/s at config 1, 56 / 64 / 80
+        measured 186.4 / 186.8 / 184.2 at config 3; profiles/r03_early_fetch.txt); 0 / False switches it off again."""
         if not early_max and early_max is not None:
             self._early = None
             return
@@ -573,7 +573,7 @@ class ShadowKVCache_CPU:
             raise RuntimeError("early fetch needs the prefilled state with the V table in pinned host memory, at most 65,536 "
                                "landmarks and at most 256 resident slots per head")
         L = lib()
-        E = int(early_max) if early_max else (20 if self.num_key_value_groups <= 4 else 48)
+        E = int(early_max) if early_max else (28 if self.num_key_value_groups <= 4 else 64)
         E = max(1, min(E, 128))
         n_lm, n_chunks = self.k_landmark.shape[-2], self.v_cache_cpu.shape[-2]
         nbytes = int(L.skv_early_state_bytes(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E))
