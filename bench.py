@@ -513,7 +513,7 @@ def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
                     steps, "" if early is None else " (early fetch off for this measurement: all miss bytes cross the link inside the launch)"))
 
 
-def run_call_order(model, ctx, steps, warmup, walk_step, seed):
+def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True):
     """The drop-in path: DecoderLM.decode_step(fused=False) = the reference's call order (inference -> layer_compute:
     pre_attention_compute, apply_rotary_pos_emb, update_kv_cache, get_retrieval_position_ids, get_value_cache under
     copy_stream || get_key_cache, attention, post_attention_compute; models/base.py:315-341, models/llama.py:354-427),
@@ -525,6 +525,8 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed):
     model.query_hook = walk
     tok = torch.randint(0, model.cfg.vocab_size, (model.batch_size, 1), device=model.device)
     hits = torch.zeros((), device=model.device, dtype=torch.float64)
+    lazy_before = cache.lazy_value_fetch
+    cache.lazy_value_fetch = bool(lazy_v)
     try:
         def step():
             nonlocal tok
@@ -543,12 +545,15 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed):
         dt = time.perf_counter() - t0
     finally:
         model.query_hook = None
+        cache.lazy_value_fetch = lazy_before
         rewind(model, ctx)
     return dict(value=round(steps * model.batch_size / dt, 2), ms_per_step=round(dt / steps * 1e3, 4),
                 chunk_hit_rate=round((float(hits) - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets), 4),
-                steps=steps, warmup=warmup, launch_mode="eager",
+                steps=steps, warmup=warmup, launch_mode="eager", lazy_value_fetch=bool(lazy_v),
                 note="decode_step(fused=False): reference call order through layer_compute / copy_stream / the "
-                     "reference-shaped cache methods (what INTEGRATION.md's three changed imports run)")
+                     "reference-shaped cache methods (what INTEGRATION.md's three changed imports run)"
+                     + ("; kv_cache.lazy_value_fetch = True: get_value_cache returns its view, the get_key_cache call behind it "
+                        "moves K and V in one launch" if lazy_v else ""))
 
 
 def free_model():
@@ -597,6 +602,8 @@ def main():
                     help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
                          "top-k; -1 = the default for the shape (32 for G <= 4, 96 for G = 8), 0 = off")
     ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
+    ap.add_argument("--strict-call-order", action="store_true",
+                    help="--mode call_order with kv_cache.lazy_value_fetch off (get_value_cache launches its own fetch under copy_stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
@@ -628,7 +635,7 @@ def main():
         if world > 1 or full or bs != 1:
             print("--mode call_order: one GPU, one sequence, ShadowKV attention", file=sys.stderr)
             sys.exit(2)
-        r = run_call_order(model, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank)
+        r = run_call_order(model, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, lazy_v=not args.strict_call_order)
         head = dict(value=r["value"], ms_per_step=r["ms_per_step"], hit_rate=r["chunk_hit_rate"], mode="call_order",
                     slack_ring=False, elapsed_local=r["ms_per_step"] * 1e-3 * args.steps, steps=args.steps)
     else:
@@ -677,6 +684,8 @@ def main():
             if ref_set and bs == 1:
                 extras["value_call_order"] = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step,
                                                             seed=99 + rank)
+                strict = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False)
+                extras["value_call_order"]["without_lazy_value_fetch"] = dict(value=strict["value"], ms_per_step=strict["ms_per_step"])
                 if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
                     r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
                                    seed=99 + rank)

@@ -371,6 +371,20 @@ SKV_EXPORT int skv_select_chunks_inplace_early(const void* q, const void* landma
                               int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
                               void* early_state, const void* v_host, long long host_block_stride, int n_chunks,
                               int early_max, float margin, skv_stream_t stream);
+/* The same pair for the reference's slot order: skv_select_chunks / skv_fetch_kv with the early state (arguments as there,
+ * then the early arguments; `groups` = q_heads / heads).  select_sets <= 256. */
+SKV_EXPORT int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                              int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
+                              int blocks, int groups, int n_landmarks, int select_sets, float alpha, void* early_state,
+                              const void* v_host, long long host_block_stride, int n_chunks, int early_max, float margin,
+                              skv_stream_t stream);
+SKV_EXPORT int skv_fetch_kv_early(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
+                              const int32_t* offsets, void* k_cache, const void* k_temp, const void* v_host, void* v_cache,
+                              const void* v_temp, int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets,
+                              int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              const void* early_state, int groups, int n_landmarks, int n_chunks, int early_max,
+                              skv_stream_t stream);
 SKV_EXPORT int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,

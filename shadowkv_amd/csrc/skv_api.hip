@@ -32,7 +32,7 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
                        const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp,
                        long long v_host_stride, long long v_stride, long long v_off, hipStream_t st,
-                       const AttnLaunch* attn);
+                       const AttnLaunch* attn, const EarlyConsume* early = nullptr);
 int skv_launch_attn_merge(const void* ws, const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, int splits,
                           hipStream_t st);
 int skv_launch_stage_hits(void* k_buf, void* k_temp, void* v_buf, void* v_temp, const int32_t* offsets,
@@ -344,6 +344,53 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
     return finish(skv_launch_topk_resident(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
                                            selected_out, dst_slots, blocks, n_landmarks, select_sets, resident_sets, slot_age,
                                            st, &eh));
+}
+
+// reference slot order (skv_select_chunks / skv_fetch_kv) with the early fetch
+int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                            int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
+                            int blocks, int groups, int n_landmarks, int select_sets, float alpha, void* early_state,
+                            const void* v_host, long long host_block_stride, int n_chunks, int early_max, float margin,
+                            skv_stream_t stream) {
+    if (!q || !landmarks || !landmark_idx || !cached_pos_ids || !offsets || !cnts || !workspace) return SKV_ERR_ARG;
+    if (!early_state || !v_host || (host_block_stride % 8)) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
+    if (n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
+    if (n_landmarks > 65536 || select_sets > 256 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+    EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
+                  es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
+                  (n_landmarks + 255) / 256, n_landmarks, select_sets, n_chunks, early_max};
+    int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
+    if (rc != SKV_OK) return rc;
+    rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
+                                       n_landmarks, st, &eh);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_topk_resident(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, offsets, cnts,
+                                           selected_out, nullptr, blocks, n_landmarks, select_sets, select_sets, nullptr, st,
+                                           &eh));
+}
+
+int skv_fetch_kv_early(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids, const int32_t* cnts,
+                       const int32_t* offsets, void* k_cache, const void* k_temp, const void* v_host, void* v_cache,
+                       const void* v_temp, int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets,
+                       int chunk_size, long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                       long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                       const void* early_state, int groups, int n_landmarks, int n_chunks, int early_max,
+                       skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !chunk_ids || !cnts || !offsets || !k_cache || !k_temp || !v_host || !v_cache || !v_temp)
+        return SKV_ERR_ARG;
+    if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
+    const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max};
+    return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, k_temp, offsets, nullptr, v_host, v_cache, v_temp,
+                                     host_block_stride, cache_stride_h, (long long)sparse_start * head_dim,
+                                     (hipStream_t)stream, nullptr, &ec));
 }
 
 int skv_select_from_scores(const void* scores, int score_stride, const int64_t* landmark_idx, int64_t* cached_pos_ids,

@@ -20,6 +20,14 @@ struct AttnLaunch {
     int early_chunks, early_max;
 };
 
+// Consumer side of the speculative early V fetch for the launches without the attention role (skv_fetch_kv*): same meaning as
+// the early_* fields of AttnLaunch.
+struct EarlyConsume {
+    const short* early_of;
+    const void* early_staging;
+    int early_chunks, early_max;
+};
+
 // Hooks of the speculative early V fetch in the selection launches (skv_select.hip, roles in skv_early.h); dthr_in null = off.
 //   scan:      a landmark slot whose logit reaches dthr_in[b][g] for some query head g is FLAGGED (it would have made the
 //              previous step's top-k): per tile the first SKV_EARLY_K flagged slots go to flag_slot, their number to flag_cnt.

@@ -271,6 +271,17 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
             loffs[k] = hit_offsets[(size_t)bh2 * S + i];
             ldi[k] = dst_slots ? dst_slots[(size_t)bh2 * S + i] : i;
         }
+        // speculative early V fetch (skv_early.h): chunks already staged in HBM (one more dependent lookup, then no PCIe)
+        int lsrc[4] = {-1, -1, -1, -1};
+        if (ar.early_of != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = blk * 8 + k * 2 + rsub;
+                const int c = min(max(loffs[k], 0), ar.early_chunks - 1);
+                const int e = ar.early_of[(size_t)bh2 * ar.early_chunks + c];
+                lsrc[k] = (i < S && i >= cnt2 && loffs[k] == c && e < ar.early_max) ? e : -1;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = blk * 8 + k * 2 + rsub;
@@ -280,7 +291,8 @@ __global__ __launch_bounds__(AG > 0 ? 512 : 256, AG > 0 ? 2 : 1) void skv_rebuil
             lact[k] = moved_hit || miss;
             // unconditional load through a selected pointer (a load under `if` is followed by vmcnt(0): the four PCIe
             // round trips of a thread would be serialised); inactive rows read a valid, unused row of the cache
-            const u32x4* src = miss ? v_host + ((long long)bh2 * v_host_stride_u128 + (long long)off * 128 + unit)
+            const u32x4* src = miss ? (lsrc[k] >= 0 ? ar.early_staging + (((long long)bh2 * ar.early_max + lsrc[k]) * 128 + unit)
+                                                    : v_host + ((long long)bh2 * v_host_stride_u128 + (long long)off * 128 + unit))
                                : moved_hit ? v_temp + (((long long)bh2 * S + i) * 128 + unit)
                                            : v_buf + ((long long)bh2 * v_stride_u128 + v_off_u128 + unit);
             lv[k] = *src;
@@ -574,7 +586,7 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
                        int C, long long cs_stride, long long out_stride_b, long long out_stride_h,
                        long long out_stride_s, int out_row0, int mode, const void* hit_temp, const int32_t* hit_offsets,
                        const int32_t* dst_slots, const void* v_host, void* v_buf, const void* v_temp, long long v_host_stride,
-                       long long v_stride, long long v_off, hipStream_t st, const AttnLaunch* attn) {
+                       long long v_stride, long long v_off, hipStream_t st, const AttnLaunch* attn, const EarlyConsume* early) {
     if (head_dim != RB_D || C < 1 || S < 1) return SKV_ERR_UNSUPPORTED;
     if (R != 160 && R != 128 && R != 96 && R != 64) return SKV_ERR_UNSUPPORTED;  // instantiated ranks (LDS pitch fits <= 160)
     if ((out_stride_s % 8) || (out_stride_h % 8) || (out_stride_b % 8)) return SKV_ERR_ARG;
@@ -590,6 +602,13 @@ int skv_launch_rebuild(const void* U, const void* SV, const void* cos_sin, const
         land_blocks = attn ? 0 : (S + 7) / 8;     // attention role: the rebuild tiles land their own V chunks
     }
     AttnRole ar{};
+    if (early && !attn) {            // (with the attention role the early fields arrive in AttnLaunch)
+        if (!early->early_of || !early->early_staging || early->early_chunks < 1 || early->early_max < 1 || !v_buf) return SKV_ERR_ARG;
+        ar.early_of = early->early_of;
+        ar.early_staging = (const u32x4*)early->early_staging;
+        ar.early_chunks = early->early_chunks;
+        ar.early_max = early->early_max;
+    }
     int attn_g = 0;
     size_t smem_all = smem;
     if (attn) {

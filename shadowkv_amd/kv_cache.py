@@ -221,11 +221,19 @@ class ShadowKVCache_CPU:
         self.output = torch.zeros(bs, kv, self.sparse_budget, D, device=self.device, dtype=dtype)
         self._staged_layer = -1
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
-        self._early = None               # speculative early V fetch (enable_early_fetch): per-layer states, side stream, events
+        self._early = None               # speculative early V fetch (enable_early_fetch): per-layer states
+        # Reference call order (get_value_cache under copy_stream, then get_key_cache, base.py:326-338): with this flag
+        # get_value_cache only returns its view and the get_key_cache call that follows for the same layer moves K AND V
+        # in ONE launch on its stream (fetch_kv: rebuild tiles and landing workgroups side by side) - nothing runs on
+        # copy_stream, the fork / join around it waits for nothing.  Valid for callers that do not read the V view before
+        # get_key_cache has been called, which is the reference's order; off by default.
+        self.lazy_value_fetch = False
+        self._pending_v = None           # (layer_idx, position_ids) of a deferred get_value_cache
+        self._early_pub = None           # layer whose selection published an early-fetch list (consumed by fetch_kv)
         # measurement hook (bench.py): a list -> every fetch launch of the in-place path is bracketed by two events on the
         # current stream and (start, end, layer) is appended; None (default): nothing is recorded
         self.fetch_events = None
-        self.copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+        self._copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
     def print_stats(self):
@@ -409,6 +417,7 @@ class ShadowKVCache_CPU:
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
         self._reference_layout_only("get_retrieval_position_ids")
+        self._flush_pending_v()              # (a deferred V fetch reads the offsets / cnts this call is about to rewrite)
         lv = self._layer(layer_idx)
         self.cnts = lv.cnts
         if self.incoming_q_len != 1:
@@ -419,10 +428,23 @@ class ShadowKVCache_CPU:
         if self._select_ws is None:
             self.H2D()
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
-        check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
-                                      ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
-                                      self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
-              "get_retrieval_position_ids")
+        ea = self._early
+        self._early_pub = None
+        if ea is not None and self.lazy_value_fetch:
+            # early fetch in the reference's slot order: only when its consumer (fetch_kv, reached through the deferred
+            # get_value_cache + get_key_cache pair) follows; the plain mover ignores the staging buffer
+            vhost = self.v_cache_cpu[layer_idx]
+            check(lib().skv_select_chunks_early(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
+                                                ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
+                                                self.select_sets, 1.0 / math.sqrt(128), ptr(ea["states"][layer_idx]),
+                                                ptr(vhost), vhost.stride(1), ea["n_chunks"], ea["E"], ea["margin"],
+                                                current_stream_handle()), "get_retrieval_position_ids (early)")
+            self._early_pub = layer_idx
+        else:
+            check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
+                                          ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
+                                          self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
+                  "get_retrieval_position_ids")
         self._stage_hits(layer_idx)
         return lv.pos
 
@@ -450,6 +472,10 @@ class ShadowKVCache_CPU:
         self._reference_layout_only("get_value_cache")
         lv = self._layer(layer_idx)
         vhost, vbuf = lv.vhost, lv.vbuf
+        self._flush_pending_v()
+        if self.lazy_value_fetch:
+            self._pending_v = (layer_idx, position_ids)
+            return vbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
         check(lib().skv_land_chunks(ptr(vhost), ptr(vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
                                     vhost.stride(1), vbuf.stride(1), self.sparse_start * self.head_dim,
                                     self.block_num, self.select_sets, current_stream_handle()), "get_value_cache")
@@ -461,9 +487,26 @@ class ShadowKVCache_CPU:
         self._reference_layout_only("get_key_cache")
         lv = self._layer(layer_idx)
         kbuf = lv.kbuf
+        if self._pending_v is not None and self._pending_v[0] == layer_idx:
+            self._pending_v = None
+            self.fetch_kv(layer_idx, position_ids, cos_sin_cache)        # K rebuild || V fetch, one launch, this stream
+            return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+        self._flush_pending_v()
         tensor_op.rebuild_keys(lv.U, lv.SV, cos_sin_cache, position_ids, self.cnts, kbuf,
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+
+    def _flush_pending_v(self):
+        """A get_value_cache deferred by lazy_value_fetch that was not followed by the same layer's get_key_cache: its V
+        chunks are moved now, on the current stream."""
+        if self._pending_v is None:
+            return
+        layer_idx, _ = self._pending_v
+        self._pending_v = None
+        lv = self._layer(layer_idx)
+        check(lib().skv_land_chunks(ptr(lv.vhost), ptr(lv.vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
+                                    lv.vhost.stride(1), lv.vbuf.stride(1), self.sparse_start * self.head_dim,
+                                    self.block_num, self.select_sets, current_stream_handle()), "get_value_cache (deferred)")
 
     def fetch_kv(self, layer_idx, position_ids, cos_sin_cache):
         """get_value_cache + get_key_cache of one layer as a single launch on the current stream (K rebuild
@@ -474,12 +517,18 @@ class ShadowKVCache_CPU:
         vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
-        check(lib().skv_fetch_kv(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(position_ids), ptr(self.cnts),
-                                 ptr(self.offsets), ptr(kbuf), ptr(self._temp_k), ptr(vhost), ptr(vbuf),
-                                 ptr(self._temp_v), U.shape[0], self.num_key_value_heads, U.shape[1], self.head_dim,
-                                 self.rank, self.select_sets, self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0),
-                                 kbuf.stride(1), kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2,
-                                 vhost.stride(1), current_stream_handle()), "fetch_kv")
+        args = (ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(position_ids), ptr(self.cnts),
+                ptr(self.offsets), ptr(kbuf), ptr(self._temp_k), ptr(vhost), ptr(vbuf),
+                ptr(self._temp_v), U.shape[0], self.num_key_value_heads, U.shape[1], self.head_dim,
+                self.rank, self.select_sets, self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0),
+                kbuf.stride(1), kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1))
+        ea = self._early
+        if ea is not None and getattr(self, "_early_pub", None) == layer_idx:   # this step's selection published a list
+            self._early_pub = None
+            check(lib().skv_fetch_kv_early(*args, ptr(ea["states"][layer_idx]), self.num_key_value_groups, ea["n_lm"],
+                                           ea["n_chunks"], ea["E"], current_stream_handle()), "fetch_kv (early)")
+        else:
+            check(lib().skv_fetch_kv(*args, current_stream_handle()), "fetch_kv")
 
     # ------------------------------------------------------------------ decode, in-place layout (MI355X-first)
     def select_fetch_inplace(self, layer_idx, query_states, cos_sin_cache):
@@ -557,6 +606,16 @@ class ShadowKVCache_CPU:
         head, V table in pinned host memory."""
         return (self.k_landmark is not None and self.k_landmark.shape[-2] <= 65536 and self.resident_sets <= 256
                 and self.v_cache_cpu is not None and self.v_cache_cpu.is_pinned())
+
+    @property
+    def copy_stream(self):
+        """The stream the reference's host code runs get_value_cache under (base.py:326-338).  With lazy_value_fetch nothing
+        is launched there: the property then hands out the CURRENT stream, so the host code's wait_stream / stream switch
+        become same-queue operations instead of two cross-queue hops per layer (measured: 160 -> 163 tokens/s with the
+        deferred launch alone, see bench.py value_call_order)."""
+        if self.lazy_value_fetch and self._copy_stream is not None:
+            return torch.cuda.current_stream(self.device)
+        return self._copy_stream
 
     def enable_early_fetch(self, early_max=None, margin=0.0):
         """Speculative early V fetch for select_fetch_attend_inplace (csrc/skv_early.hip): the scan launch flags the

@@ -794,3 +794,49 @@ def test_captured_step_with_early_fetch_replays_like_the_eager_step_without():
     assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
     pulled = sum(int(m2.kv_cache.early_fetch_counts(l).sum()) for l in range(m2.num_layers))
     assert pulled > 0, "nothing was pulled early in the last captured step"
+
+
+@pytest.mark.parametrize("glm", [False, True])
+def test_lazy_value_fetch_in_the_reference_call_order_changes_no_bit(glm):
+    """kv_cache.lazy_value_fetch: get_value_cache (called under copy_stream, base.py:326-338) only returns its view and the
+    get_key_cache call behind it moves K and V in one launch.  Same tokens, logits and cache bytes as the two separate
+    launches on two streams; a get_value_cache that is NOT followed by its get_key_cache is flushed by the next cache call."""
+    steps = 5
+    m1, llama = _make(glm=glm, seed=6)
+    m2, _ = _make(glm=glm, seed=6)
+    m3, _ = _make(glm=glm, seed=6)
+    m2.kv_cache.lazy_value_fetch = True
+    m3.kv_cache.lazy_value_fetch = True
+    m3.kv_cache.enable_early_fetch(early_max=8)          # ... and with the early fetch in the reference's slot order
+    table = llama.make_walk_table(m1, steps, seed=3)
+    outs = []
+    for m in (m1, m2, m3):
+        walk_i = [0]
+        m.query_hook = lambda l, q, _t=table, _i=walk_i: torch.addcmul(_t[_i[0]][l], q, torch.zeros((), device=DEV, dtype=q.dtype))
+        t = torch.tensor([[17]], device=DEV)
+        toks = []
+        for i in range(steps):
+            walk_i[0] = i
+            t = m.decode_step(t, temperature=0.0, fused=False)
+            toks.append(int(t))
+        m.query_hook = None
+        outs.append(toks)
+    torch.cuda.synchronize()
+    assert outs[0] == outs[1] == outs[2]
+    for mx in (m2, m3):
+        assert torch.equal(m1.kv_cache.position_ids, mx.kv_cache.position_ids)
+        assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), mx.kv_cache.k_cache_buffer.view(torch.int16))
+        assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), mx.kv_cache.v_cache_buffer.view(torch.int16))
+    assert sum(int(m3.kv_cache.early_fetch_counts(l).sum()) for l in range(m3.num_layers)) > 0, "nothing was pulled early"
+    # a deferred get_value_cache without its get_key_cache: flushed by the next call, V bytes as in the eager cache
+    c1, c2 = m1.kv_cache, m2.kv_cache
+    q = (torch.randn(1, 8, 1, 128, device=DEV) * 1.5).bfloat16()
+    for c in (c1, c2):
+        ids = c.get_retrieval_position_ids(layer_idx=0, query_states=q)
+        c.get_value_cache(0, ids)
+    assert c2._pending_v is not None
+    c2.get_retrieval_position_ids(layer_idx=1, query_states=q)          # any further call
+    c1.get_retrieval_position_ids(layer_idx=1, query_states=q)
+    torch.cuda.synchronize()
+    assert c2._pending_v is None
+    assert torch.equal(c1.v_cache_buffer[0].view(torch.int16), c2.v_cache_buffer[0].view(torch.int16))
