@@ -126,7 +126,12 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
     }
 
     const bool flag_wave = ABL == 0 && eh.dthr_in != nullptr && wave == (G < WAVES ? G : 0);
-    __shared__ float s_dth[G];
+    // early fetch: the heads' thresholds.  Uniform addresses (kernel argument + blockIdx): scalar loads into SGPRs, requested
+    // here and consumed behind the barrier - no vector register is held across the loop (the G = 4 kernel sits exactly at
+    // its 64-VGPR budget) and no wave waits for them
+    float dth[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) dth[g] = (ABL == 0 && eh.dthr_in != nullptr) ? eh.dthr_in[(size_t)blockIdx.y * G + g] : INFINITY;
     const int row0 = t * SKV_TILE + wave * (4 * ITERS) + rsel;
     u32x4 x[ITERS];
     auto request = [&](int i) __attribute__((always_inline)) {
@@ -136,9 +141,6 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
     };
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) request(i);
-    // early fetch: the flag wave's thresholds travel behind its row requests into LDS (read behind the barrier; no register
-    // is held across the loop: the G = 4 kernel sits exactly at its 64-VGPR budget)
-    if (flag_wave && lane < G) s_dth[lane] = eh.dthr_in[(size_t)b * G + lane];
     if (ABL == 1) {   // memory stream only: fold the loaded words so the loads stay, skip all arithmetic
         uint32_t f = 0;
 #pragma unroll
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         unsigned fl = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float th = s_dth[g];
+            const float th = dth[g];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (t * SKV_TILE + c0 + k < N && bf2f(sD[g][c0 + k]) >= th) fl |= 1u << k;
