@@ -529,3 +529,32 @@ def test_early_fetch_changes_no_bit(kv_heads, glm):
     assert pulled[0] == 0, "no thresholds before the first step: nothing may be flagged"
     assert max(pulled[1:]) > 0, f"the prediction never fired: {pulled}"
     assert pulled[3] == 0 or pulled[3] <= pulled[2], pulled
+
+
+@pytest.mark.parametrize("early_max,margin", [(1, 0.0), (128, 0.0), (16, -1.0), (16, 5.0)])
+def test_early_fetch_extremes_change_no_bit(early_max, margin):
+    """The early fetch at its limits: one chunk per head, the maximum of 128, a margin that flags far too much (-1: every slot
+    within e of the threshold - the lists overflow and most pulled chunks are not selected) and one that flags nothing (+5).
+    Outputs and caches stay those of the plain steps."""
+    ca, cs, g = _headline_cache(8, False, L=16384, seed=29)
+    cb, _, _ = _headline_cache(8, False, L=16384, seed=29)
+    ca.enable_early_fetch(early_max=early_max, margin=margin)
+    kv_len = ca.sparse_end + 2
+    q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
+    pulled = 0
+    for step in range(5):
+        q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+        oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        torch.cuda.synchronize()
+        n = ca.early_fetch_counts(0)
+        assert int(n.max()) <= early_max
+        pulled += int(n.sum())
+        assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), step
+        assert torch.equal(ca.position_ids, cb.position_ids)
+        assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16)), step
+        assert torch.equal(ca.k_cache_buffer.view(torch.int16), cb.k_cache_buffer.view(torch.int16)), step
+    if margin >= 5.0:
+        assert pulled == 0, "a threshold 5 above the k-th logit must flag nothing"
+    else:
+        assert pulled > 0
