@@ -198,18 +198,25 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float th = dth[g];
+            const u32x2 v = *reinterpret_cast<const u32x2*>(&sD[g][c0]);     // the lane's 4 logits of head g: one LDS read
+            fl |= (bf_lo(v[0]) >= th ? 1u : 0u) | (bf_hi(v[0]) >= th ? 2u : 0u) | (bf_lo(v[1]) >= th ? 4u : 0u) |
+                  (bf_hi(v[1]) >= th ? 8u : 0u);
+        }
+        if ((t + 1) * SKV_TILE > N) {                        // last tile: columns past the row are not slots
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (t * SKV_TILE + c0 + k < N && bf2f(sD[g][c0 + k]) >= th) fl |= 1u << k;
+                if (t * SKV_TILE + c0 + k >= N) fl &= ~(1u << k);
         }
         int base = 0;
+        if (__ballot(fl != 0u) != 0ull) {                    // (most tiles of most steps have a few flagged slots; many have none)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned long long bal = __ballot((fl >> k) & 1u);
-            const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-            if (((fl >> k) & 1u) && pos < SKV_EARLY_K)
-                eh.flag_slot[((size_t)b * T + t) * SKV_EARLY_K + pos] = t * SKV_TILE + c0 + k;
-            base += __builtin_popcountll(bal);
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long bal = __ballot((fl >> k) & 1u);
+                const int pos = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (((fl >> k) & 1u) && pos < SKV_EARLY_K)
+                    eh.flag_slot[((size_t)b * T + t) * SKV_EARLY_K + pos] = t * SKV_TILE + c0 + k;
+                base += __builtin_popcountll(bal);
+            }
         }
         if (lane == 0) eh.flag_cnt[(size_t)b * T + t] = min(base, SKV_EARLY_K);
     }
