@@ -146,6 +146,20 @@ def test_decode_methods_fail_loudly_without_gpu(built):
         cache.get_retrieval_position_ids(0, inp["q_steps"][0])
 
 
+def test_round3_options_host_logic(built):
+    """Host side of the round-3 options: the early fetch refuses a cache whose V table is not in pinned host memory (a CPU
+    build has none) instead of degrading; lazy_value_fetch is off by default, a deferred get_value_cache is remembered per
+    layer, and copy_stream only becomes the current stream with the flag set."""
+    _, cache, _, _ = built
+    assert cache._early is None and not cache.early_fetch_supported()
+    with pytest.raises(RuntimeError, match="pinned host memory"):
+        cache.enable_early_fetch()
+    cache.enable_early_fetch(early_max=0)              # "off" is always accepted
+    assert cache._early is None
+    assert cache.lazy_value_fetch is False and cache._pending_v is None
+    assert cache.copy_stream is cache._copy_stream     # (None on a CPU build)
+
+
 def test_resident_set_option_lays_out_the_buffers_and_keeps_the_reference_state():
     """resident_sets > select_sets (host logic only): the sparse region grows to resident_sets chunks with the generated rows
     behind it, the first select_sets slots hold exactly what the default cache holds (same ids, same K / V rows), the extra
