@@ -230,6 +230,7 @@ class ShadowKVCache_CPU:
         self.lazy_value_fetch = False
         self._pending_v = None           # (layer_idx, position_ids) of a deferred get_value_cache
         self._early_pub = None           # layer whose selection published an early-fetch list (consumed by fetch_kv)
+        self.fetch_kv_follows = False    # set by a caller that calls fetch_kv right behind get_retrieval_position_ids
         # measurement hook (bench.py): a list -> every fetch launch of the in-place path is bracketed by two events on the
         # current stream and (start, end, layer) is appended; None (default): nothing is recorded
         self.fetch_events = None
@@ -430,9 +431,10 @@ class ShadowKVCache_CPU:
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
         ea = self._early
         self._early_pub = None
-        if ea is not None and self.lazy_value_fetch:
-            # early fetch in the reference's slot order: only when its consumer (fetch_kv, reached through the deferred
-            # get_value_cache + get_key_cache pair) follows; the plain mover ignores the staging buffer
+        if ea is not None and (self.lazy_value_fetch or self.fetch_kv_follows) and self.block_num <= 8:
+            # early fetch in the reference's slot order: only when its consumer (fetch_kv - reached through the deferred
+            # get_value_cache + get_key_cache pair, or called next by the fused step, which says so with fetch_kv_follows)
+            # follows; the plain mover ignores the staging buffer
             vhost = self.v_cache_cpu[layer_idx]
             check(lib().skv_select_chunks_early(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
                                                 ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,

@@ -314,7 +314,11 @@ class DecoderLM:
                     c.select_fetch_inplace(l, q, self.cos_sin_cache)
                     slot_args = c.attend_slot_args()
                 elif not full:
-                    ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+                    c.fetch_kv_follows = True            # (lets the selection publish an early-fetch list: fetch_kv consumes it)
+                    try:
+                        ids = c.get_retrieval_position_ids(layer_idx=l, query_states=q)
+                    finally:
+                        c.fetch_kv_follows = False
                     c.fetch_kv(l, ids, self.cos_sin_cache)
                 attn = tensor_op.sparse_attention_decode(q, kbuf, vbuf, kv_len=kv_len, kv_len_dev=kv_len_dev, **slot_args)
             o = tensor_op.linear_decode(attn.reshape(bs, 1, self.hidden_size), layer.wo)

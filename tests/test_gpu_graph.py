@@ -769,12 +769,14 @@ def test_sample_topk_keeps_every_logit_tied_with_the_kth_value(V):
     assert set(draws[:, 1].tolist()) == kept1
 
 
-def test_captured_step_with_early_fetch_replays_like_the_eager_step_without():
+@pytest.mark.parametrize("layout,overlap", [("inplace", True), ("reference", False)])
+def test_captured_step_with_early_fetch_replays_like_the_eager_step_without(layout, overlap):
     """Speculative early V fetch inside the captured step (extra workgroups of the normalise and top-k launches, staged chunks
-    consumed by the fetch launch): same tokens and cache bytes as the eager step without it, and the prediction fires."""
+    consumed by the fetch launch): same tokens and cache bytes as the eager step without it, and the prediction fires - in the
+    in-place layout with the attention inside the fetch launch and in the reference's slot order (fetch_kv)."""
     steps = 8
-    m1, llama = _make(layout="inplace", overlap=True)
-    m2, _ = _make(layout="inplace", overlap=True)
+    m1, llama = _make(layout=layout, overlap=overlap)
+    m2, _ = _make(layout=layout, overlap=overlap)
     assert m2.kv_cache.can_overlap_attention()
     m2.kv_cache.enable_early_fetch(early_max=8)
     table = llama.make_walk_table(m1, steps, seed=3)
