@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The fused merge + O projection launch against the two launches it replaces: time per call (20 captured back to back over
+"""(Record of a rejected experiment: needs the library built WITH tools/rejected/merge_oproj_fused.hip and its tensor_op wrappers,
+see profiles/r03_merge_oproj_fused.txt.)  The fused merge + O projection launch against the two launches it replaces: time per call (20 captured back to back over
 4 weight sets) and, with the diagnostic library (make -C shadowkv_amd/csrc stamps; SKV_LIB_PATH=.../libshadowkv_hip_stamps.so),
 in-kernel phase stamps."""
 import ctypes, os, sys
