@@ -385,6 +385,14 @@ SKV_EXPORT int skv_fetch_kv_early(const void* U, const void* SV, const void* cos
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               const void* early_state, int groups, int n_landmarks, int n_chunks, int early_max,
                               skv_stream_t stream);
+/* skv_fetch_kv_inplace (the plain in-place launch: batches, standalone attention) with the early state. */
+SKV_EXPORT int skv_fetch_kv_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                              const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host, void* v_cache,
+                              int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets, int chunk_size,
+                              long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                              long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                              const void* early_state, int groups, int n_landmarks, int n_chunks, int early_max,
+                              skv_stream_t stream);
 SKV_EXPORT int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,

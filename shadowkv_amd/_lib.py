@@ -37,6 +37,7 @@ _SIGS = {
     "skv_apply_rotary_pos_emb": (c_int, [c_p] * 5 + [c_int] * 14 + [c_p]),
     "skv_select_workspace_bytes": (c_sz, [c_int] * 3),
     "skv_select_chunks": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f, c_p]),
+    "skv_fetch_kv_inplace_early": (c_int, [c_p] * 9 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll] + [c_p] + [c_int] * 4 + [c_p]),
     "skv_select_chunks_early": (c_int, [c_p] * 9 + [c_int] * 4 + [c_f] + [c_p, c_p, c_ll, c_int, c_int, c_f, c_p]),
     "skv_fetch_kv_early": (c_int, [c_p] * 11 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll] + [c_p] + [c_int] * 4 + [c_p]),
     "skv_select_chunks_inplace": (c_int, [c_p] * 10 + [c_int] * 5 + [c_p, c_f, c_p]),

@@ -455,6 +455,25 @@ int skv_fetch_kv_inplace(const void* U, const void* SV, const void* cos_sin, con
                                      (long long)sparse_start * head_dim, (hipStream_t)stream, nullptr));
 }
 
+int skv_fetch_kv_inplace_early(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
+                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host, void* v_cache,
+                               int batch_size, int heads, int seq_len, int head_dim, int rank, int select_sets, int chunk_size,
+                               long long cos_sin_stride, long long cache_stride_b, long long cache_stride_h,
+                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
+                               const void* early_state, int groups, int n_landmarks, int n_chunks, int early_max,
+                               skv_stream_t stream) {
+    if (!U || !SV || !cos_sin || !miss_ids || !dst_slots || !cnts || !k_cache || !v_host || !v_cache) return SKV_ERR_ARG;
+    if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
+    const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max};
+    return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
+                                     rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
+                                     cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
+                                     v_cache, nullptr, host_block_stride, cache_stride_h,
+                                     (long long)sparse_start * head_dim, (hipStream_t)stream, nullptr, &ec));
+}
+
 static int fetch_kv_attn_inplace_impl(const void* U, const void* SV, const void* cos_sin, const int32_t* miss_ids,
                               const int32_t* dst_slots, const int32_t* cnts, void* k_cache, const void* v_host,
                               void* v_cache, const void* q, void* attn_workspace, const int32_t* kv_len_dev, int kv_len,

@@ -121,8 +121,8 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     }
 }
 
-// Pull role: SKV_EARLY_PULL_WGS workgroups of THREADS threads per (batch, head) b, workgroup `part` takes the published
-// chunks e = part, part + PULL_WGS, ...  (How fast host memory can be read depends on how many CUs ask: one workgroup per
+// Pull role: eh.pull_wgs workgroups of THREADS threads per (batch, head) b (SKV_EARLY_PULL_WGS for one sequence, 1 for batches,
+// which have a head per CU and more anyway), workgroup `part` takes the published chunks e = part, part + pull_wgs, ...  (How fast host memory can be read depends on how many CUs ask: one workgroup per
 // head - 4 CUs at GLM-4's shape - pulled 393 KB in 15 us = 26 GB/s and stretched the top-k launch from 12.7 to 18.5 us; with
 // four per head it ends with the top-k, 12.6 us.)  s_sel: EF_MAX_E ints.
 #define SKV_EARLY_PULL_WGS 4
@@ -136,13 +136,14 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
     // under `if` would be followed by a wait for the PCIe round trip)
     const u32x4* const hb = reinterpret_cast<const u32x4*>(eh.v_host) + (long long)b * eh.v_host_stride_u128;
     u32x4* const sb = reinterpret_cast<u32x4*>(eh.staging) + (size_t)b * E * 128;
-    const int mine = (n_sel - part + SKV_EARLY_PULL_WGS - 1) / SKV_EARLY_PULL_WGS;      // chunks of this workgroup
+    const int PW = eh.pull_wgs;
+    const int mine = (n_sel - part + PW - 1) / PW;           // chunks of this workgroup
     for (int r0 = 0; r0 * THREADS < mine * 128; r0 += 8) {
         u32x4 v[8];
         int dst[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = (r0 + k) * THREADS + tid, e = (idx >> 7) * SKV_EARLY_PULL_WGS + part, u = idx & 127;
+            const int idx = (r0 + k) * THREADS + tid, e = (idx >> 7) * PW + part, u = idx & 127;
             const bool on = e < n_sel;
             dst[k] = on ? e * 128 + u : -1;
             const u32x4* src = on ? hb + (long long)s_sel[e] * 128 + u : reinterpret_cast<const u32x4*>(sb) + u;

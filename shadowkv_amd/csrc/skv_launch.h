@@ -53,6 +53,7 @@ struct EarlyHooks {
     long long v_host_stride_u128;
     void* staging;
     int T, N, R, n_chunks, E;
+    int pull_wgs;               // pull workgroups per (batch, head) in the top-k launch (4 for one sequence, 1 for batches)
 };
 
 // Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.

@@ -784,10 +784,10 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
     const int tid = threadIdx.x;
-    if (eh.staging != nullptr && (int)blockIdx.x >= (int)gridDim.x / (1 + SKV_EARLY_PULL_WGS)) {
+    if (eh.staging != nullptr && (int)blockIdx.x >= (int)gridDim.x / (1 + eh.pull_wgs)) {
         // early fetch: the blocks behind the B selection blocks pull (skv_early.h)
-        const int p = (int)blockIdx.x - (int)gridDim.x / (1 + SKV_EARLY_PULL_WGS);
-        skv_early_pull_role<T2_THREADS>(eh, p / SKV_EARLY_PULL_WGS, p % SKV_EARLY_PULL_WGS, tid, smem);
+        const int p = (int)blockIdx.x - (int)gridDim.x / (1 + eh.pull_wgs);
+        skv_early_pull_role<T2_THREADS>(eh, p / eh.pull_wgs, p % eh.pull_wgs, tid, smem);
         return;
     }
     const int b = blockIdx.x;
@@ -1186,7 +1186,8 @@ static int launch_topk2(const void* score, int score_stride, const int64_t* lm_i
     const bool pull = eh.staging != nullptr && eh.dthr_in != nullptr;
     EarlyHooks ek = eh;
     if (!pull) ek.staging = nullptr;
-    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(pull ? (1 + SKV_EARLY_PULL_WGS) * B : B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
+    ek.pull_wgs = B <= 8 ? SKV_EARLY_PULL_WGS : 1;
+    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(pull ? (1 + ek.pull_wgs) * B : B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
                        cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age, ek);
     return SKV_OK;
 }

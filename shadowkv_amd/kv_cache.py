@@ -431,7 +431,7 @@ class ShadowKVCache_CPU:
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
         ea = self._early
         self._early_pub = None
-        if ea is not None and (self.lazy_value_fetch or self.fetch_kv_follows) and self.block_num <= 8:
+        if ea is not None and (self.lazy_value_fetch or self.fetch_kv_follows):
             # early fetch in the reference's slot order: only when its consumer (fetch_kv - reached through the deferred
             # get_value_cache + get_key_cache pair, or called next by the fused step, which says so with fetch_kv_follows)
             # follows; the plain mover ignores the staging buffer
@@ -551,23 +551,32 @@ class ShadowKVCache_CPU:
             self._dst_slots = torch.zeros_like(self.offsets)
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
         L, st = lib(), current_stream_handle()
-        check(L.skv_select_chunks_inplace(ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
-                                          ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
-                                          ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
-                                          self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                                          self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128), st),
-              "select_chunks_inplace")
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
+        sel_args = (ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
+                    ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
+                    ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
+                    self.num_key_value_groups, lm.shape[-2], self.select_sets,
+                    self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
+        ea = self._early
+        if ea is not None:
+            check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
+                                                    ea["n_chunks"], ea["E"], ea["margin"], st), "select_chunks_inplace_early")
+        else:
+            check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
         ev0 = self._fetch_event()
-        check(L.skv_fetch_kv_inplace(ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
-                                     ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), U.shape[0],
-                                     self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
-                                     self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
-                                     kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1), st),
-              "fetch_kv_inplace")
+        fetch_args = (ptr(U), ptr(SV), ptr(cos_sin_cache), ptr(self.offsets), ptr(self._dst_slots),
+                      ptr(self.cnts), ptr(kbuf), ptr(vhost), ptr(vbuf), U.shape[0],
+                      self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
+                      self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
+                      kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1))
+        if ea is not None:
+            check(L.skv_fetch_kv_inplace_early(*fetch_args, ptr(ea["states"][layer_idx]), self.num_key_value_groups, ea["n_lm"],
+                                               ea["n_chunks"], ea["E"], st), "fetch_kv_inplace_early")
+        else:
+            check(L.skv_fetch_kv_inplace(*fetch_args, st), "fetch_kv_inplace")
         self._fetch_event(ev0, layer_idx)
 
     def _fetch_event(self, start=None, layer_idx=None):
@@ -634,7 +643,12 @@ class ShadowKVCache_CPU:
             raise RuntimeError("early fetch needs the prefilled state with the V table in pinned host memory, at most 65,536 "
                                "landmarks and at most 256 resident slots per head")
         L = lib()
-        E = int(early_max) if early_max else (28 if self.num_key_value_groups <= 4 else 64)
+        if early_max:
+            E = int(early_max)
+        elif self.block_num > 8:          # batches: what the link moves during their top-k launch, spread over all heads
+            E = max(1, 256 // self.block_num)
+        else:
+            E = 28 if self.num_key_value_groups <= 4 else 64
         E = max(1, min(E, 128))
         n_lm, n_chunks = self.k_landmark.shape[-2], self.v_cache_cpu.shape[-2]
         nbytes = int(L.skv_early_state_bytes(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E))

@@ -842,3 +842,30 @@ def test_lazy_value_fetch_in_the_reference_call_order_changes_no_bit(glm):
     torch.cuda.synchronize()
     assert c2._pending_v is None
     assert torch.equal(c1.v_cache_buffer[0].view(torch.int16), c2.v_cache_buffer[0].view(torch.int16))
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_early_fetch_on_the_plain_in_place_path_changes_no_bit(batch):
+    """The early fetch through select_fetch_inplace (the plain in-place fetch launch + standalone attention: one sequence
+    without the overlapped attention, and batches - one pull workgroup per head there): tokens, bookkeeping and cache bytes
+    of a few fused steps against the same steps without it; chunks are pulled early."""
+    steps = 6
+    m1, llama = _make(layout="inplace", overlap=False, batch=batch)
+    m2, _ = _make(layout="inplace", overlap=False, batch=batch)
+    m2.kv_cache.enable_early_fetch(early_max=6)
+    table = llama.make_walk_table(m1, steps, seed=3)
+    toks = []
+    for m in (m1, m2):
+        t = torch.arange(5, 5 + batch, device=DEV).view(batch, 1)
+        out = []
+        for i in range(steps):
+            t = m.decode_step(t, temperature=0.0, q_table=table[i])
+            out.append(t.view(-1).tolist())
+        toks.append(out)
+    torch.cuda.synchronize()
+    assert toks[0] == toks[1]
+    assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
+    assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
+    assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
+    pulled = sum(int(m2.kv_cache.early_fetch_counts(l).sum()) for l in range(m2.num_layers))
+    assert pulled > 0, "nothing was pulled early in the last step"
