@@ -189,6 +189,8 @@ def run_decode(model, args, ctx, steps, warmup, walk_step, seed, world=1, pin_hi
                                            q_table=walk.qb if args.query_mode == "walk" else None)
             if not full:
                 hits_eager.add_(cache._cnts_layers.sum())
+        if args.no_step_sync:
+            return None                               # (diagnostic: tokens stay on the device, one sync at the end)
         return next_token[:, -1].tolist()             # per-step host sync, as base.py:635
 
     for _ in range(warmup):
@@ -610,6 +612,9 @@ def main():
                          "part of a batch's PCIe-bound step")
     ap.add_argument("--strict-call-order", action="store_true",
                     help="--mode call_order with kv_cache.lazy_value_fetch off (get_value_cache launches its own fetch under copy_stream)")
+    ap.add_argument("--no-step-sync", action="store_true",
+                    help="diagnostic: do not read the token back every step (the reference's loop does, base.py:635, and so does "
+                         "every reported number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
