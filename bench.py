@@ -241,10 +241,18 @@ def measure_score_kernel(model, iters=3):
     st = torch.cuda.current_stream().cuda_stream
     L = _lib.lib()
 
+    ea = getattr(cache, "_early", None)
+
     def run_all():
         for l in range(model.num_layers):
-            _lib.check(L.skv_score_landmarks(q.data_ptr(), cache.k_landmark[l].data_ptr(), D.data_ptr(), pm.data_ptr(),
-                                             ps.data_ptr(), B, G, N, 1.0 / math.sqrt(128), st), "score")
+            if ea is not None:      # the scan as the step launches it: with the early fetch's flag pass
+                _lib.check(L.skv_score_landmarks_early(q.data_ptr(), cache.k_landmark[l].data_ptr(),
+                                                       cache.k_landmark_idx[l].data_ptr(), D.data_ptr(), pm.data_ptr(),
+                                                       ps.data_ptr(), B, G, N, 1.0 / math.sqrt(128),
+                                                       ea["states"][l].data_ptr(), ea["n_chunks"], ea["E"], st), "score")
+            else:
+                _lib.check(L.skv_score_landmarks(q.data_ptr(), cache.k_landmark[l].data_ptr(), D.data_ptr(), pm.data_ptr(),
+                                                 ps.data_ptr(), B, G, N, 1.0 / math.sqrt(128), st), "score")
     run_all()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -371,6 +371,11 @@ SKV_EXPORT int skv_select_chunks_inplace_early(const void* q, const void* landma
                               int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age, float alpha,
                               void* early_state, const void* v_host, long long host_block_stride, int n_chunks,
                               int early_max, float margin, skv_stream_t stream);
+/* skv_score_landmarks as the early selection launches it (the scan with its flag pass; the flags go to the state and are
+ * rewritten by the next selection): the kernel bench.py times for the roofline when the early fetch is on. */
+SKV_EXPORT int skv_score_landmarks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, void* logits,
+                              float* part_max, float* part_sum, int blocks, int groups, int n_landmarks, float alpha,
+                              void* early_state, int n_chunks, int early_max, skv_stream_t stream);
 /* The same pair for the reference's slot order: skv_select_chunks / skv_fetch_kv with the early state (arguments as there,
  * then the early arguments; `groups` = q_heads / heads).  select_sets <= 256. */
 SKV_EXPORT int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,

@@ -53,6 +53,7 @@ _SIGS = {
     "skv_select_from_scores": (c_int, [c_p, c_int] + [c_p] * 6 + [c_int] * 4 + [c_p, c_p]),
     "skv_sample_topk_advance": (c_int, [c_p, c_ll] + [c_int] * 3 + [c_f, c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
+    "skv_score_landmarks_early": (c_int, [c_p] * 6 + [c_int] * 3 + [c_f, c_p, c_int, c_int, c_p]),
     "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
     "skv_fetch_kv": (c_int, [c_p] * 11 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_p]),
     "skv_stage_hit_chunks": (c_int, [c_p] * 6 + [c_ll] * 2 + [c_int] * 2 + [c_p]),

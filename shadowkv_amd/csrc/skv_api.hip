@@ -410,6 +410,19 @@ int skv_score_landmarks(const void* q, const void* landmarks, void* logits, floa
                                    (hipStream_t)stream));
 }
 
+int skv_score_landmarks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, void* logits, float* part_max,
+                              float* part_sum, int blocks, int groups, int n_landmarks, float alpha, void* early_state,
+                              int n_chunks, int early_max, skv_stream_t stream) {
+    if (!q || !landmarks || !landmark_idx || !logits || !part_max || !part_sum || !early_state) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+    EarlyHooks eh{};
+    eh.dthr_in = es.dthr; eh.flag_cnt = es.flag_cnt; eh.flag_slot = es.flag_slot; eh.G = groups; eh.lm_idx = landmark_idx;
+    eh.T = (n_landmarks + 255) / 256; eh.N = n_landmarks; eh.n_chunks = n_chunks; eh.E = early_max;
+    return finish(skv_launch_score(q, landmarks, logits, part_max, part_sum, blocks, groups, n_landmarks, alpha,
+                                   (hipStream_t)stream, &eh));
+}
+
 int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,
                      const int32_t* cnts, void* k_cache, int batch_size, int heads, int seq_len, int head_dim,
                      int rank, int select_sets, int chunk_size, long long cos_sin_stride,
