@@ -354,7 +354,7 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
  * early_state: skv_early_state_bytes(...) bytes of device memory PER LAYER, initialised once with skv_early_state_init;
  * n_chunks = chunks per head of the host table (ids in landmark_idx are < n_chunks); early_max <= 128; margin is added to
  * the logit thresholds (0: flag what would have made the previous top-k; > 0: fewer).  n_landmarks <= 65,536,
- * resident_sets <= 256, n_chunks <= 262,144; other shapes: SKV_ERR_UNSUPPORTED (-2), use the plain pair.
+ * resident_sets <= 1,024, n_chunks <= 262,144; other shapes: SKV_ERR_UNSUPPORTED (-2), use the plain pair.
  * The two calls are a PAIR: a state whose last step was not consumed by skv_fetch_kv_attn_inplace_early may still be used (the
  * next skv_select_chunks_inplace_early rewrites it), but skv_fetch_kv_attn_inplace_early must only follow the
  * skv_select_chunks_inplace_early of the same step and state.

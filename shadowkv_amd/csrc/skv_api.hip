@@ -329,7 +329,7 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
     if (n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
     // the list (normalise launch) and the pull (second-generation top-k launch) exist for these shapes only; a list that is
     // published MUST be pulled, so other shapes are refused here instead of degrading silently
-    if (n_landmarks > 65536 || resident_sets > 256 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
+    if (n_landmarks > 65536 || resident_sets > 1024 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);

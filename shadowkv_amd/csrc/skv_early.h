@@ -50,7 +50,7 @@ static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
     return ((size_t)(n_chunks + 31) / 32 + 64) * sizeof(int);
 }
 
-// One workgroup of THREADS threads for (batch, head) b.  R <= THREADS resident slots, T * SKV_EARLY_K <= EF_MAX_CAND.
+// One workgroup of THREADS threads for (batch, head) b.  R <= 4 * THREADS resident slots, T * SKV_EARLY_K <= EF_MAX_CAND.
 // Two dependent round trips (flag entries + resident ids + last step's list, then the slot -> chunk id gathers), one block
 // scan.  Candidate i = (tile i / K, entry i % K) is real when its entry index is below the tile's count; a thread's
 // candidates are i = c * THREADS + tid, and every load is issued unconditionally (a load under `if` would be followed by
@@ -79,11 +79,15 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
             tcnt[c] = eh.flag_cnt[(size_t)b * T + i / SKV_EARLY_K];
         }
     }
-    const long long my_res = tid < R ? eh.resident[(size_t)b * R + tid] : -1ll;
+    long long my_res[4];                                   // resident ids of slots tid, tid + THREADS, ... (R <= 4 * THREADS)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
     if (tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
     __syncthreads();
-    if (my_res >= 0 && my_res < n_chunks) atomicOr(&s_bits[my_res >> 5], 1 << (my_res & 31));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (my_res[k] >= 0 && my_res[k] < n_chunks) atomicOr(&s_bits[my_res[k] >> 5], 1 << (my_res[k] & 31));
     // ---- round trip 2: slot -> chunk id
     long long id[CPT];
     unsigned realm = 0;

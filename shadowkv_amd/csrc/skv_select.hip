@@ -1155,7 +1155,7 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
     const int gx = (T + tpb - 1) / tpb;
     // early fetch: one more workgroup per head (the list of chunks to pull); it is the only one that uses dynamic LDS
     const bool prep = eh.dthr_in != nullptr;
-    if (prep && (T > 256 || eh.R > 256)) return SKV_ERR_UNSUPPORTED;
+    if (prep && (T > 256 || eh.R > 1024)) return SKV_ERR_UNSUPPORTED;
     const size_t smem = prep ? skv_early_prep_lds_bytes(eh.n_chunks) : 0;
     if (smem > 60 * 1024) return SKV_ERR_UNSUPPORTED;
     const int prep_block = prep ? gx : -1;

@@ -613,9 +613,9 @@ class ShadowKVCache_CPU:
                 and self.block_num <= 8)
 
     def early_fetch_supported(self):
-        """Shapes the early-fetch roles are built for (csrc/skv_early.h): <= 65,536 landmarks and <= 256 resident slots per
+        """Shapes the early-fetch roles are built for (csrc/skv_early.h): <= 65,536 landmarks and <= 1,024 resident slots per
         head, V table in pinned host memory."""
-        return (self.k_landmark is not None and self.k_landmark.shape[-2] <= 65536 and self.resident_sets <= 256
+        return (self.k_landmark is not None and self.k_landmark.shape[-2] <= 65536 and self.resident_sets <= 1024
                 and self.v_cache_cpu is not None and self.v_cache_cpu.is_pinned())
 
     @property
@@ -641,7 +641,7 @@ class ShadowKVCache_CPU:
             return
         if not self.early_fetch_supported():
             raise RuntimeError("early fetch needs the prefilled state with the V table in pinned host memory, at most 65,536 "
-                               "landmarks and at most 256 resident slots per head")
+                               "landmarks and at most 1,024 resident slots per head")
         L = lib()
         if early_max:
             E = int(early_max)

@@ -869,3 +869,28 @@ def test_early_fetch_on_the_plain_in_place_path_changes_no_bit(batch):
     assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
     pulled = sum(int(m2.kv_cache.early_fetch_counts(l).sum()) for l in range(m2.num_layers))
     assert pulled > 0, "nothing was pulled early in the last step"
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_early_fetch_with_a_larger_resident_set_changes_no_bit(overlap):
+    """The early fetch with resident_sets = 80 > select_sets = 32 (least-recently-selected replacement): the list role drops
+    every RESIDENT chunk, selected this step or not; tokens, slot map, ages and cache bytes equal the same steps without it."""
+    steps, R = 8, 80
+    m1, llama = _make(layout="inplace", overlap=overlap, resident_sets=R)
+    m2, _ = _make(layout="inplace", overlap=overlap, resident_sets=R)
+    m2.kv_cache.enable_early_fetch(early_max=6)
+    table = llama.make_walk_table(m1, steps, seed=3)
+    toks = []
+    for m in (m1, m2):
+        t = torch.tensor([[17]], device=DEV)
+        out = []
+        for i in range(steps):
+            t = m.decode_step(t, temperature=0.0, q_table=table[i])
+            out.append(int(t))
+        toks.append(out)
+    torch.cuda.synchronize()
+    assert toks[0] == toks[1]
+    assert torch.equal(m1.kv_cache.position_ids, m2.kv_cache.position_ids)
+    assert torch.equal(m1.kv_cache._slot_age, m2.kv_cache._slot_age)
+    assert torch.equal(m1.kv_cache.k_cache_buffer.view(torch.int16), m2.kv_cache.k_cache_buffer.view(torch.int16))
+    assert torch.equal(m1.kv_cache.v_cache_buffer.view(torch.int16), m2.kv_cache.v_cache_buffer.view(torch.int16))
