@@ -844,14 +844,15 @@ def test_lazy_value_fetch_in_the_reference_call_order_changes_no_bit(glm):
     assert torch.equal(c1.v_cache_buffer[0].view(torch.int16), c2.v_cache_buffer[0].view(torch.int16))
 
 
-@pytest.mark.parametrize("batch", [1, 3])
-def test_early_fetch_on_the_plain_in_place_path_changes_no_bit(batch):
+@pytest.mark.parametrize("batch,overlap", [(1, False), (3, False), (4, True), (5, True)])
+def test_early_fetch_on_the_plain_in_place_path_changes_no_bit(batch, overlap):
     """The early fetch through select_fetch_inplace (the plain in-place fetch launch + standalone attention: one sequence
-    without the overlapped attention, and batches - one pull workgroup per head there): tokens, bookkeeping and cache bytes
-    of a few fused steps against the same steps without it; chunks are pulled early."""
+    without the overlapped attention, and batches - one pull workgroup per head there) and through the fused launch with
+    several sequences (4 x 2 KV heads = 8 blocks still take the fused launch, 5 x 2 the plain one): tokens, bookkeeping and
+    cache bytes of a few fused steps against the same steps without it; chunks are pulled early."""
     steps = 6
-    m1, llama = _make(layout="inplace", overlap=False, batch=batch)
-    m2, _ = _make(layout="inplace", overlap=False, batch=batch)
+    m1, llama = _make(layout="inplace", overlap=overlap, batch=batch)
+    m2, _ = _make(layout="inplace", overlap=overlap, batch=batch)
     m2.kv_cache.enable_early_fetch(early_max=6)
     table = llama.make_walk_table(m1, steps, seed=3)
     toks = []
