@@ -637,6 +637,8 @@ class ShadowKVCache_CPU:
         BASELINE shapes: 20 / 24 / 28 / 36 measured 220.0 / 220.5 / 221.3 / 220.6 tokens/s at config 1, 56 / 64 / 80
         measured 186.4 / 186.8 / 184.2 at config 3; profiles/r03_early_fetch.txt); 0 / False switches it off again."""
         if not early_max and early_max is not None:
+            if self._early is not None:      # a captured step may still point at the state buffers: they stay allocated
+                self._early_retired = getattr(self, "_early_retired", []) + [self._early]
             self._early = None
             return
         if not self.early_fetch_supported():
