@@ -662,6 +662,8 @@ class ShadowKVCache_CPU:
         offs = (ctypes.c_longlong * 8)()
         check(L.skv_early_state_offsets(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs), "early_state_offsets")
         torch.cuda.synchronize(self.device)
+        if self._early is not None:
+            self._early_retired = getattr(self, "_early_retired", []) + [self._early]
         self._early = dict(states=states, E=E, margin=float(margin), n_lm=n_lm, n_chunks=n_chunks, offsets=list(offs))
 
     def early_fetch_counts(self, layer_idx):
