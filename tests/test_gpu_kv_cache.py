@@ -558,3 +558,24 @@ def test_early_fetch_extremes_change_no_bit(early_max, margin):
         assert pulled == 0, "a threshold 5 above the k-th logit must flag nothing"
     else:
         assert pulled > 0
+
+
+@pytest.mark.parametrize("kv_heads,glm", [(8, False), (4, True)])
+def test_early_fetch_with_thresholds_that_jump_changes_no_selection(kv_heads, glm):
+    """Query scales that move the k-th score far up and far down between steps, so that the early fetch's thresholds (taken
+    from the previous step) flag nearly everything or nothing: selection, bookkeeping and caches equal the plain steps'."""
+    ca, cs, g = _headline_cache(kv_heads, glm, L=16384, seed=31)
+    cb, _, _ = _headline_cache(kv_heads, glm, L=16384, seed=31)
+    ca.enable_early_fetch(early_max=4)
+    kv_len = ca.sparse_end + 2
+    base = torch.randn(1, 32, 1, 128, device=DEV, generator=g)
+    for step, scale in enumerate([1.5, 1.5, 0.2, 0.2, 3.0, 0.05, 1.0, 4.0, 4.0, 0.5]):
+        q = ((base + 0.2 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)) * scale).bfloat16()
+        oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        torch.cuda.synchronize()
+        assert torch.equal(ca.cnts, cb.cnts), (step, scale)
+        assert torch.equal(ca.offsets, cb.offsets), (step, scale)
+        assert torch.equal(ca.position_ids, cb.position_ids), (step, scale)
+        assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), (step, scale)
+    assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16))
