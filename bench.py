@@ -525,7 +525,7 @@ def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
                     steps, "" if early is None else " (early fetch off for this measurement: all miss bytes cross the link inside the launch)"))
 
 
-def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True):
+def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inplace=False):
     """The drop-in path: DecoderLM.decode_step(fused=False) = the reference's call order (inference -> layer_compute:
     pre_attention_compute, apply_rotary_pos_emb, update_kv_cache, get_retrieval_position_ids, get_value_cache under
     copy_stream || get_key_cache, attention, post_attention_compute; models/base.py:315-341, models/llama.py:354-427),
@@ -537,8 +537,9 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True):
     model.query_hook = walk
     tok = torch.randint(0, model.cfg.vocab_size, (model.batch_size, 1), device=model.device)
     hits = torch.zeros((), device=model.device, dtype=torch.float64)
-    lazy_before = cache.lazy_value_fetch
+    lazy_before, inplace_before = cache.lazy_value_fetch, cache.inplace_methods
     cache.lazy_value_fetch = bool(lazy_v)
+    cache.inplace_methods = bool(inplace and lazy_v)
     try:
         def step():
             nonlocal tok
@@ -557,11 +558,11 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True):
         dt = time.perf_counter() - t0
     finally:
         model.query_hook = None
-        cache.lazy_value_fetch = lazy_before
+        cache.lazy_value_fetch, cache.inplace_methods = lazy_before, inplace_before
         rewind(model, ctx)
     return dict(value=round(steps * model.batch_size / dt, 2), ms_per_step=round(dt / steps * 1e3, 4),
                 chunk_hit_rate=round((float(hits) - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets), 4),
-                steps=steps, warmup=warmup, launch_mode="eager", lazy_value_fetch=bool(lazy_v),
+                steps=steps, warmup=warmup, launch_mode="eager", lazy_value_fetch=bool(lazy_v), inplace_methods=bool(inplace and lazy_v),
                 note="decode_step(fused=False): reference call order through layer_compute / copy_stream / the "
                      "reference-shaped cache methods (what INTEGRATION.md's three changed imports run)"
                      + ("; kv_cache.lazy_value_fetch = True: get_value_cache returns its view, the get_key_cache call behind it "
@@ -618,6 +619,8 @@ def main():
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "
                          "off by default: measured 595.3 vs 594.9 tokens/s at bs 8, 769.3 vs 761.0 at bs 24 - the selection is a small "
                          "part of a batch's PCIe-bound step")
+    ap.add_argument("--inplace-methods", action="store_true",
+                    help="--mode call_order with kv_cache.inplace_methods (reference-shaped methods on the in-place layout)")
     ap.add_argument("--strict-call-order", action="store_true",
                     help="--mode call_order with kv_cache.lazy_value_fetch off (get_value_cache launches its own fetch under copy_stream)")
     ap.add_argument("--no-step-sync", action="store_true",
@@ -654,7 +657,8 @@ def main():
         if world > 1 or full or bs != 1:
             print("--mode call_order: one GPU, one sequence, ShadowKV attention", file=sys.stderr)
             sys.exit(2)
-        r = run_call_order(model, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, lazy_v=not args.strict_call_order)
+        r = run_call_order(model, ctx, args.steps, args.warmup, args.walk_step, seed=99 + rank, lazy_v=not args.strict_call_order,
+                           inplace=args.inplace_methods)
         head = dict(value=r["value"], ms_per_step=r["ms_per_step"], hit_rate=r["chunk_hit_rate"], mode="call_order",
                     slack_ring=False, elapsed_local=r["ms_per_step"] * 1e-3 * args.steps, steps=args.steps)
     else:
@@ -705,6 +709,11 @@ def main():
                                                             seed=99 + rank)
                 strict = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False)
                 extras["value_call_order"]["without_lazy_value_fetch"] = dict(value=strict["value"], ms_per_step=strict["ms_per_step"])
+                inpl = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, inplace=True)
+                extras["value_call_order"]["with_inplace_methods"] = dict(
+                    value=inpl["value"], ms_per_step=inpl["ms_per_step"],
+                    note="kv_cache.inplace_methods: the same calls on the in-place layout (no staging launch for moved hits; same "
+                         "chunk sets, slot order differs from the reference's)")
                 if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
                     r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
                                    seed=99 + rank)

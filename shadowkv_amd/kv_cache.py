@@ -228,6 +228,12 @@ class ShadowKVCache_CPU:
         # copy_stream, the fork / join around it waits for nothing.  Valid for callers that do not read the V view before
         # get_key_cache has been called, which is the reference's order; off by default.
         self.lazy_value_fetch = False
+        # With lazy_value_fetch: the reference-shaped methods on the IN-PLACE layout (hits keep their slots, no staging launch
+        # for moved hits).  get_retrieval_position_ids then returns the slot -> chunk map in slot order instead of "hits by old
+        # slot, then misses by id" - the same SET; host code that only hands the ids back to get_value_cache / get_key_cache
+        # (base.py:320-338) does not see the difference.  Off by default: the default reproduces the reference's order.
+        self.inplace_methods = False
+        self._last_cos_sin = None
         self._pending_v = None           # (layer_idx, position_ids) of a deferred get_value_cache
         self._early_pub = None           # layer whose selection published an early-fetch list (consumed by fetch_kv)
         self.fetch_kv_follows = False    # set by a caller that calls fetch_kv right behind get_retrieval_position_ids
@@ -417,8 +423,14 @@ class ShadowKVCache_CPU:
         Returns position_ids[layer_idx] (reordered in place: hits by old slot, then misses by id);
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
-        self._reference_layout_only("get_retrieval_position_ids")
         self._flush_pending_v()              # (a deferred V fetch reads the offsets / cnts this call is about to rewrite)
+        if self.inplace_methods:
+            if not self.lazy_value_fetch or self.resident_sets != self.select_sets:
+                raise RuntimeError("inplace_methods needs lazy_value_fetch (K and V move in one in-place launch) and "
+                                   "resident_sets == select_sets (the views cover the whole sparse region)")
+            self._select_inplace(layer_idx, query_states)
+            return self.position_ids[layer_idx]
+        self._reference_layout_only("get_retrieval_position_ids")
         lv = self._layer(layer_idx)
         self.cnts = lv.cnts
         if self.incoming_q_len != 1:
@@ -471,7 +483,8 @@ class ShadowKVCache_CPU:
         region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream): lands the
         hit chunks staged by get_retrieval_position_ids and pulls the misses over PCIe with plain 16-B loads
         (49-56 GB/s measured, the DMA ceiling; tools/pcie_probe.hip)."""
-        self._reference_layout_only("get_value_cache")
+        if not self.inplace_methods:
+            self._reference_layout_only("get_value_cache")
         lv = self._layer(layer_idx)
         vhost, vbuf = lv.vhost, lv.vbuf
         self._flush_pending_v()
@@ -486,13 +499,20 @@ class ShadowKVCache_CPU:
     def get_key_cache(self, layer_idx, position_ids, rope_func, cos_sin_cache):
         """Hit chunks moved to their new slots, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
         region (kv_cache.py:1108-1176), one launch.  `rope_func` is unused, as in the reference."""
-        self._reference_layout_only("get_key_cache")
+        if not self.inplace_methods:
+            self._reference_layout_only("get_key_cache")
         lv = self._layer(layer_idx)
         kbuf = lv.kbuf
+        self._last_cos_sin = cos_sin_cache
         if self._pending_v is not None and self._pending_v[0] == layer_idx:
             self._pending_v = None
-            self.fetch_kv(layer_idx, position_ids, cos_sin_cache)        # K rebuild || V fetch, one launch, this stream
+            if self.inplace_methods:
+                self._fetch_inplace(layer_idx, cos_sin_cache)            # K rebuild || V fetch in place, one launch
+            else:
+                self.fetch_kv(layer_idx, position_ids, cos_sin_cache)    # K rebuild || V fetch, one launch, this stream
             return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+        if self.inplace_methods:
+            raise RuntimeError("inplace_methods: get_key_cache must follow get_value_cache of the same layer (base.py:326-338)")
         self._flush_pending_v()
         tensor_op.rebuild_keys(lv.U, lv.SV, cos_sin_cache, position_ids, self.cnts, kbuf,
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
@@ -505,6 +525,11 @@ class ShadowKVCache_CPU:
             return
         layer_idx, _ = self._pending_v
         self._pending_v = None
+        if self.inplace_methods:             # (the in-place launch moves K and V together)
+            if self._last_cos_sin is None:
+                raise RuntimeError("inplace_methods: a deferred get_value_cache needs a get_key_cache call to carry it out")
+            self._fetch_inplace(layer_idx, self._last_cos_sin)
+            return
         lv = self._layer(layer_idx)
         check(lib().skv_land_chunks(ptr(lv.vhost), ptr(lv.vbuf), ptr(self._temp_v), ptr(self.offsets), ptr(self.cnts),
                                     lv.vhost.stride(1), lv.vbuf.stride(1), self.sparse_start * self.head_dim,
@@ -540,6 +565,10 @@ class ShadowKVCache_CPU:
         Same selected set, same rows in the sparse region - in a different slot order, which attention does not see.
         4 launches (score, normalize, top-k/diff, rebuild||fetch) instead of 5; position_ids[layer_idx] stays the
         slot -> chunk map (invariant: slot i holds chunk position_ids[i])."""
+        self._select_inplace(layer_idx, query_states)
+        self._fetch_inplace(layer_idx, cos_sin_cache)
+
+    def _select_inplace(self, layer_idx, query_states):
         if query_states.shape[-2] != 1:
             raise ValueError("decode-time selection expects q_len == 1")
         self.incoming_q_len = 1
@@ -551,7 +580,6 @@ class ShadowKVCache_CPU:
             self._dst_slots = torch.zeros_like(self.offsets)
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
         L, st = lib(), current_stream_handle()
-        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
         sel_args = (ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
                     ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
@@ -564,6 +592,11 @@ class ShadowKVCache_CPU:
                                                     ea["n_chunks"], ea["E"], ea["margin"], st), "select_chunks_inplace_early")
         else:
             check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
+
+    def _fetch_inplace(self, layer_idx, cos_sin_cache):
+        L, st = lib(), current_stream_handle()
+        kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
+        vhost = self.v_cache_cpu[layer_idx]
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
         ev0 = self._fetch_event()
@@ -572,6 +605,7 @@ class ShadowKVCache_CPU:
                       self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
                       self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
                       kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1))
+        ea = self._early
         if ea is not None:
             check(L.skv_fetch_kv_inplace_early(*fetch_args, ptr(ea["states"][layer_idx]), self.num_key_value_groups, ea["n_lm"],
                                                ea["n_chunks"], ea["E"], st), "fetch_kv_inplace_early")
