@@ -36,6 +36,11 @@ WORKLOADS = {
     "llama3_1048k_131072": ("LLAMA_3_8B_1048K", 131072, 2048),
     "glm4_200k": ("GLM_4_9B_1M", 200 * 1024, 2048),
     "llama31_4k": ("LLAMA_3_1_8B", 4104, 256),
+    # the reference's own other regimes (test/e2e.py:35-116, index.html:167-259): budget 1024 at 60K (S = 128, 24 outlier chunks)
+    # and budget 4096 at 244K (S = 512, 96 outlier chunks), and its fourth model (G = 8 with NeoX RoPE)
+    "llama31_60k_b1024": ("LLAMA_3_1_8B", 60 * 1024, 1024),
+    "llama31_244k_b4096": ("LLAMA_3_1_8B", 244 * 1024, 4096),
+    "yi9b_122k": ("YI_9B_200K", 122 * 1024, 2048),
     # not a BASELINE.json configuration: the 1M-token model at its full context on one GPU (10.7 GB of U, 8.6 GB of
     # landmarks in HBM, 69 GB of V chunks in pinned host memory)
     "llama3_1048k_full": ("LLAMA_3_8B_1048K", 1048576, 2048),
@@ -446,15 +451,51 @@ def numa_node_of_address(addr):
         return None
 
 
-def process_numa_node():
-    """NUMA node of the CPU this process runs on right now."""
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def current_cpu():
+    """The CPU this thread runs on right now (glibc sched_getcpu through ctypes: Python 3.10 has no os.sched_getcpu - which is
+    why the round-3 record said process_numa_node: null); None if it cannot be told."""
     try:
-        cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
-        if cpu is None:
-            return None
-        for d in os.listdir(f"/sys/devices/system/cpu/cpu{cpu}"):
+        if hasattr(os, "sched_getcpu"):
+            return int(os.sched_getcpu())
+        import ctypes
+        cpu = int(ctypes.CDLL(None, use_errno=True).sched_getcpu())
+        return cpu if cpu >= 0 else None
+    except Exception:
+        return None
+
+
+def process_numa_node(sys_root="/sys/devices/system"):
+    """NUMA node of the CPU this process runs on right now: the `nodeN` link in the CPU's sysfs directory or, where the kernel
+    does not expose it there (the driver's N = 1 box in round 3: the record said null), the node whose cpulist holds the CPU;
+    a machine without NUMA information in sysfs at all reports node 0 if it has CPUs online, else None."""
+    cpu = current_cpu()
+    if cpu is None:
+        return None
+    try:
+        for d in os.listdir(f"{sys_root}/cpu/cpu{cpu}"):
             if d.startswith("node") and d[4:].isdigit():
                 return int(d[4:])
+    except Exception:
+        pass
+    try:
+        nodes = [d for d in os.listdir(f"{sys_root}/node") if d.startswith("node") and d[4:].isdigit()]
+        for d in sorted(nodes, key=lambda x: int(x[4:])):
+            if cpu in _parse_cpulist(open(f"{sys_root}/node/{d}/cpulist").read()):
+                return int(d[4:])
+    except Exception:
+        pass
+    try:                                     # no node directory (NUMA off / container without it): one memory domain
+        if cpu in _parse_cpulist(open(f"{sys_root}/cpu/online").read()):
+            return 0
     except Exception:
         pass
     return None
@@ -569,6 +610,72 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inpl
                         "moves K and V in one launch" if lazy_v else ""))
 
 
+def measure_prefill_state(workload, dev):
+    """Prefill-side state builders of ONE layer at the workload's context length (not on the
+    decode clock): the rank-160 factorisation - Gram path (the default on a GPU since round 4) against the reference's
+    torch.svd call (kv_cache.py:706) on the same synthetic keys -, the native chunk-statistics pass, and prefill_kv_cache as
+    a whole with the copy of the V table to pinned host memory timed beside it.  Wall times around synchronised calls."""
+    from shadowkv_amd import llama, tensor_op
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU, gram_factorize
+    cfg_name, ctx, budget = WORKLOADS[workload]
+    cfg = getattr(llama, cfg_name)
+    kv, D, r = cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads, 160
+
+    class _Cfg:
+        num_hidden_layers = 1
+        num_attention_heads = cfg.num_attention_heads
+        num_key_value_heads = kv
+        hidden_size = cfg.hidden_size
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn(1, ctx, 256, device=dev, generator=g)
+    b = torch.randn(1, 256, kv * D, device=dev, generator=g) * torch.logspace(0, -2, 256, device=dev).view(1, 256, 1)
+    k_pre = (a @ b + 0.01 * torch.randn(1, ctx, kv * D, device=dev, generator=g)).bfloat16()       # [1, L, kv*D]: a spectrum with a tail
+    del a, b
+    out = dict(context=ctx, kv_heads=kv, note="one layer; wall time around synchronised calls; keys = rank-256 signal + noise")
+    cache = ShadowKVCache_CPU(_Cfg, batch_size=1, max_length=ctx, device=dev, sparse_budget=budget, chunk_size=8, rank=r)
+    out["get_svd_default_gram"] = round(timed(lambda: cache.get_svd(k_pre, 0), 3), 2)
+    kf = k_pre.float()
+    u_g, sv_g = gram_factorize(kf, r)
+    cache.svd_mode = "svd"
+    t0 = time.perf_counter()
+    cache.get_svd(k_pre, 0)                                           # (one call: 2 s at 122K; its first call also loads rocSOLVER)
+    torch.cuda.synchronize()
+    first = (time.perf_counter() - t0) * 1e3
+    out["get_svd_torch_svd"] = round(min(first, timed(lambda: cache.get_svd(k_pre, 0), 1)), 1)
+    # reconstruction of the two factorisations from the stored bf16 factors, relative to the RMS key value (SURVEY.md 8c: rtol 1e-2)
+    rec_svd = torch.einsum("blr,bhdr->blhd", cache.U[0].float(), cache.SV[0].float()).reshape(1, ctx, kv * D)
+    rec_gram = u_g.bfloat16().float() @ sv_g.bfloat16().float()
+    scale = kf.pow(2).mean().sqrt()
+    out["reconstruction_rms_gram_vs_svd_rel"] = round(float((rec_gram - rec_svd).pow(2).mean().sqrt() / scale), 6)
+    out["reconstruction_error_rel"] = dict(gram=round(float((rec_gram - kf).pow(2).mean().sqrt() / scale), 6),
+                                           svd=round(float((rec_svd - kf).pow(2).mean().sqrt() / scale), 6))
+    del rec_svd, rec_gram, u_g, sv_g, kf
+    k = k_pre.view(1, ctx, kv, D).transpose(1, 2).contiguous()           # [1, kv, L, D] (post-RoPE layout; values do not matter here)
+    v = torch.randn(1, kv, ctx, D, device=dev, generator=g).bfloat16()
+    q = torch.randn(1, cfg.num_attention_heads, 1, D, device=dev, generator=g).bfloat16()
+    chunks = (ctx // 8 - 4) - (ctx // 8 - 4) % 8
+
+    def prefill():
+        cache.prefilled_batch = 0
+        cache.kv_offset = 0
+        cache.prefill_kv_cache(v, 0, k, q)
+    out["prefill_kv_cache"] = round(timed(prefill, 3), 2)
+    out["chunk_stats_native_pass"] = round(timed(lambda: tensor_op.chunk_stats(k[:, :, :chunks * 8], 8), 5), 3)
+    out["v_table_to_pinned_host"] = round(timed(lambda: cache.v_cache_cpu[0][:, :, :ctx // 8].copy_(
+        v.reshape(1, kv, ctx // 8, 8 * D), non_blocking=True), 3), 2)
+    out["v_table_mb"] = round(v.numel() * 2 / 1e6, 1)
+    return out
+
+
 def free_model():
     import gc
     gc.collect()
@@ -580,8 +687,17 @@ def clone_args(args, **kw):
     d.update(kw)
     return argparse.Namespace(**d)
 
+DIST_BACKEND = "nccl"      # RCCL on ROCm; tests/test_dist_cpu.py drives main()'s control flow over gloo
+
+
+def setup_device(local_rank):
+    """Selects this rank's GPU and pins the process to its NUMA node; returns (device string, NUMA node or None)."""
+    torch.cuda.set_device(local_rank)
+    return f"cuda:{local_rank}", pin_to_gpu_numa_node(local_rank)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -613,7 +729,7 @@ def main():
                          "replaced - same outputs, fewer chunks over PCIe; in-place layout only)")
     ap.add_argument("--early-fetch", type=int, default=-1,
                     help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
-                         "top-k; -1 = the default for the shape (32 for G <= 4, 96 for G = 8), 0 = off")
+                         "top-k; -1 = the default for the shape (28 for G <= 4, 64 for G = 8: kv_cache.enable_early_fetch), 0 = off")
     ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
     ap.add_argument("--early-fetch-batches", type=int, default=0, choices=[0, 1],
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "
@@ -632,7 +748,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the bs 8 / bs 24 lines (the reference's published regime)")
     ap.add_argument("--no-pair", action="store_true", help="skip the e2e-style full-attention / ShadowKV pair")
     ap.add_argument("--batched", default="8,24", help="batch sizes of the `batched` entries of the default run")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -642,12 +758,13 @@ def main():
               file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    numa = pin_to_gpu_numa_node(local_rank)
+    dev, numa = setup_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if DIST_BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(DIST_BACKEND)
 
     full = args.attn == "full"
     bs = args.batch
@@ -818,6 +935,14 @@ def main():
                                                       "slots per head, attention over the 256 selected chunks as before")
         default_line = (detail and args.workload == "llama31_122k" and bs == 1 and args.layers is None and args.mode == "graph"
                         and args.layout == "inplace" and args.resident_sets is None and args.v_table == "host")
+        if default_line:
+            model = cache = None
+            free_model()
+            try:
+                out["prefill_state_ms_per_layer"] = measure_prefill_state(args.workload, dev)
+            except Exception as e:           # a diagnostic entry must not cost the line
+                out["prefill_state_ms_per_layer"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+            free_model()
         best_batched = None
         if default_line and not args.no_batched:
             # the reference's own regime (test/e2e.py:63-68, index.html:210-214: bs 24 at 122K on an A100 = 245.90 tok/s):

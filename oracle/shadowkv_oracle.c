@@ -566,6 +566,82 @@ ORACLE_API void oracle_sparse_attention(const uint16_t *q, const uint16_t *k, co
         }
 }
 
+/* a11, second mode: the softmax weights rounded to bf16 at the DEVICE KERNELS' rounding points (round 4).
+ * The reference's attention is flash-attn (models/base.py:341, un-vendored), which converts P to the input dtype (bf16)
+ * before the P.V matrix product; the device passes that run P.V on the MFMA do the same, each relative to the maximum it
+ * knows at that moment, and rescale in f32 afterwards.  Which rows are rounded, and against which maximum, is described
+ * by two per-row labels (built by the tests from the kernels' launch geometry and the selection's bookkeeping):
+ *   grp[bh][row] >= 0 : rounding group of the row; < 0: the row's weight is never rounded (VALU passes)
+ *   ord[bh][row]      : step of the row inside its group (rows of one step are rounded against the same maximum)
+ *   m_ref(i) = max{ s_j : grp_j == grp_i, ord_j <= ord_i }            (tile attention: one step per tile -> the tile maximum;
+ *                                                                       standalone pass: running maximum of a wave's 32-key steps)
+ *   weight_i = bf16( expf( s_i - m_ref(i) ) ) * exp( m_ref(i) - M )   for grp_i >= 0,   exp( s_i - M ) otherwise
+ *   out      = sum_i weight_i v_i / sum_i exp( s_i - M )              (the kernels sum the UNROUNDED p into l:
+ *                                                                       skv_attn_body.h `ps += p0 + p1`, skv_rebuild.hip `l += pk`)
+ * with s_i = f32( q . k_i * scale ) and M the row maximum; sums in double, one final rounding.  What is left between
+ * this and the device is f32 summation order, the 2-ulp error of the device's fast exp and the rare weight whose bf16
+ * rounding flips because of them. */
+ORACLE_API void oracle_sparse_attention_p16(const uint16_t *q, const uint16_t *k, const uint16_t *v, uint16_t *out,
+                                            float *out_f32, int bs, int q_heads, int kv_heads, int head_dim,
+                                            int kv_len, long kv_stride_rows, float scale, const int32_t *grp,
+                                            const int32_t *ord) {
+    int G = q_heads / kv_heads;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < bs; ++b)
+        for (int qh = 0; qh < q_heads; ++qh) {
+            int h = qh / G;
+            size_t bh = (size_t)b * kv_heads + h;
+            const uint16_t *qp = q + ((size_t)b * q_heads + qh) * head_dim;
+            const uint16_t *kp = k + bh * (size_t)kv_stride_rows * head_dim;
+            const uint16_t *vp = v + bh * (size_t)kv_stride_rows * head_dim;
+            const int32_t *gp = grp + bh * (size_t)kv_len, *op = ord + bh * (size_t)kv_len;
+            float *sc = (float *)malloc((size_t)kv_len * sizeof(float));
+            double *w = (double *)malloc((size_t)kv_len * sizeof(double));
+            int ngrp = 0, nord = 1;
+            float mx = -INFINITY;
+            for (int j = 0; j < kv_len; ++j) {
+                double acc = 0;
+                for (int d = 0; d < head_dim; ++d)
+                    acc += (double)bf2f(qp[d]) * (double)bf2f(kp[(size_t)j * head_dim + d]);
+                sc[j] = (float)(acc * (double)scale);
+                if (sc[j] > mx) mx = sc[j];
+                if (gp[j] >= ngrp) ngrp = gp[j] + 1;
+                if (gp[j] >= 0 && op[j] >= nord) nord = op[j] + 1;
+            }
+            /* m_ref table: maximum per (group, step), then the running maximum over the steps of a group */
+            float *mref = (float *)malloc((size_t)(ngrp > 0 ? ngrp : 1) * nord * sizeof(float));
+            for (long i = 0; i < (long)ngrp * nord; ++i) mref[i] = -INFINITY;
+            for (int j = 0; j < kv_len; ++j)
+                if (gp[j] >= 0) {
+                    float *m = &mref[(size_t)gp[j] * nord + (op[j] < 0 ? 0 : op[j])];
+                    if (sc[j] > *m) *m = sc[j];
+                }
+            for (int g = 0; g < ngrp; ++g)
+                for (int o = 1; o < nord; ++o)
+                    if (mref[(size_t)g * nord + o - 1] > mref[(size_t)g * nord + o]) mref[(size_t)g * nord + o] = mref[(size_t)g * nord + o - 1];
+            double den = 0;
+            for (int j = 0; j < kv_len; ++j) {
+                den += exp((double)sc[j] - (double)mx);
+                if (gp[j] >= 0) {
+                    float m = mref[(size_t)gp[j] * nord + (op[j] < 0 ? 0 : op[j])];
+                    w[j] = (double)bf2f(f2bf(expf(sc[j] - m))) * exp((double)m - (double)mx);
+                } else {
+                    w[j] = exp((double)sc[j] - (double)mx);
+                }
+            }
+            for (int d = 0; d < head_dim; ++d) {
+                double acc = 0;
+                for (int j = 0; j < kv_len; ++j) acc += w[j] * (double)bf2f(vp[(size_t)j * head_dim + d]);
+                float r = (float)(acc / den);
+                if (out) out[((size_t)b * q_heads + qh) * head_dim + d] = f2bf(r);
+                if (out_f32) out_f32[((size_t)b * q_heads + qh) * head_dim + d] = r;
+            }
+            free(mref);
+            free(w);
+            free(sc);
+        }
+}
+
 /* ------------------------------------------------------------------------- */
 /* f1: prefill-side chunk statistics (models/kv_cache.py:854-868)            */
 /* ------------------------------------------------------------------------- */

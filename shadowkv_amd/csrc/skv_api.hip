@@ -356,7 +356,7 @@ int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t*
     if (!early_state || !v_host || (host_block_stride % 8)) return SKV_ERR_ARG;
     if (blocks < 1 || n_landmarks < select_sets || select_sets < 1) return SKV_ERR_ARG;
     if (n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
-    if (n_landmarks > 65536 || select_sets > 256 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
+    if (n_landmarks > 65536 || select_sets > 1024 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);

@@ -89,33 +89,46 @@ __global__ __launch_bounds__(128) void skv_attn_combine_kernel(const float* __re
 // the split pass over the resident rows and one record per LIVE miss tile (tiles t >= cnt / 8 of `tiles`; skv_rebuild.hip
 // attends every tile it builds).  One workgroup per query head merges them.  All loads are issued at kernel entry (the
 // dead tiles' stale records are fetched too and dropped: no dependent round trip behind the hit count).
-#define MRG_MAX_REC 64
+// MAXREC = 64 (budget 2048: 24 + 32 records; static LDS) or 128 (budget 4096, S = 512: 24 + 64 records - the reference's
+// 244K regime, test/e2e.py:50-55; the records then need 67.6 KB of dynamic LDS).
+#define MRG_MAX_REC 128
+template <int MAXREC>
 __global__ __launch_bounds__(256) void skv_attn_merge_kernel(const float* __restrict__ ws, const int32_t* __restrict__ cnts,
                                                              bf16_t* __restrict__ out, int G, int splits, int tiles) {
-    __shared__ __attribute__((aligned(16))) float s_rec[MRG_MAX_REC * AT_REC];
-    __shared__ float s_wgt[MRG_MAX_REC];
-    __shared__ float s_a[2][AT_D];
-    __shared__ float s_l[2];
+    extern __shared__ __attribute__((aligned(16))) float s_mrg[];
+    float* const s_rec = s_mrg;                              // [MAXREC * AT_REC]
+    float* const s_wgt = s_rec + MAXREC * AT_REC;            // [MAXREC]
+    float (*s_a)[AT_D] = reinterpret_cast<float (*)[AT_D]>(s_wgt + MAXREC);   // [2][AT_D]
+    float* const s_l = s_wgt + MAXREC + 2 * AT_D;            // [2]
     const int bq = blockIdx.x, bh = bq / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrec = splits + tiles;
     const int cnt = cnts[bh];
     const u32x4* src = reinterpret_cast<const u32x4*>(ws + (size_t)bq * nrec * AT_REC);
     const int nvec = nrec * (AT_REC / 4);
-    u32x4 tmp[9];                                            // 64 records x 33 vectors / 256 threads
+    constexpr int NV = (MAXREC * (AT_REC / 4) + 255) / 256;  // 64 records x 33 vectors / 256 threads = 9
+    u32x4 tmp[NV];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < NV; ++k)
         if (tid + k * 256 < nvec) tmp[k] = src[tid + k * 256];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < NV; ++k)
         if (tid + k * 256 < nvec) reinterpret_cast<u32x4*>(s_rec)[tid + k * 256] = tmp[k];
     __syncthreads();
     const int t0 = cnt / 8;                                  // first tile with a miss chunk
-    // wave 0: weights exp(m_r - M) of the live records
+    // wave 0: weights exp(m_r - M) of the live records (lane l takes records l, l + 64)
     if (wave == 0) {
-        const bool live = lane < nrec && (lane < splits || lane - splits >= t0);
-        const float mr = live ? s_rec[lane * AT_REC + AT_D] : -INFINITY;
-        const float M = wave_max_dpp(mr);
-        s_wgt[lane] = (mr == -INFINITY) ? 0.f : __expf(mr - M);
+        float mr[MAXREC / 64];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXREC / 64; ++k) {
+            const int r = lane + 64 * k;
+            const bool live = r < nrec && (r < splits || r - splits >= t0);
+            mr[k] = live ? s_rec[r * AT_REC + AT_D] : -INFINITY;
+            mloc = fmaxf(mloc, mr[k]);
+        }
+        const float M = wave_max_dpp(mloc);
+#pragma unroll
+        for (int k = 0; k < MAXREC / 64; ++k) s_wgt[lane + 64 * k] = (mr[k] == -INFINITY) ? 0.f : __expf(mr[k] - M);
     }
     __syncthreads();
     {
@@ -138,8 +151,17 @@ __global__ __launch_bounds__(256) void skv_attn_merge_kernel(const float* __rest
 int skv_launch_attn_merge(const void* ws, const int32_t* cnts, void* out, int bs, int Hq, int Hkv, int S, int splits,
                           hipStream_t st) {
     if (Hkv < 1 || Hq % Hkv || S < 8 || S % 8 || splits < 1 || splits + S / 8 > MRG_MAX_REC) return SKV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(skv_attn_merge_kernel, dim3(bs * Hq), dim3(256), 0, st, (const float*)ws, cnts, (bf16_t*)out,
-                       Hq / Hkv, splits, S / 8);
+    if (splits + S / 8 <= 64) {
+        const size_t smem = (size_t)(64 * AT_REC + 64 + 2 * AT_D + 4) * sizeof(float);
+        hipLaunchKernelGGL(skv_attn_merge_kernel<64>, dim3(bs * Hq), dim3(256), smem, st, (const float*)ws, cnts, (bf16_t*)out,
+                           Hq / Hkv, splits, S / 8);
+    } else {
+        const size_t smem = (size_t)(128 * AT_REC + 128 + 2 * AT_D + 4) * sizeof(float);
+        static size_t attr_bytes[64] = {};
+        if (skv_ensure_max_lds((const void*)skv_attn_merge_kernel<128>, smem, attr_bytes) != SKV_OK) return SKV_ERR_LAUNCH;
+        hipLaunchKernelGGL(skv_attn_merge_kernel<128>, dim3(bs * Hq), dim3(256), smem, st, (const float*)ws, cnts, (bf16_t*)out,
+                           Hq / Hkv, splits, S / 8);
+    }
     return SKV_OK;
 }
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void skv_silu_and_mul_kernel(const bf16_t* __r
 
 // update_kv_cache for a handful of new tokens (/root/reference/models/kv_cache.py:1227-1271): rows [row0, row0 + incoming)
 // of both cache buffers <- the new K / V rows; rows past the buffer are dropped like the reference's zero-length slice.
-// One 256-thread block per (batch, head, new token): threads 0..15 x 2 buffers move 16 B each.
+// One 64-thread block (one wave) per (batch, head, new token): threads 0..15 x 2 buffers move 16 B each.
 __global__ __launch_bounds__(64) void skv_append_kv_kernel(const u32x4* __restrict__ k_new, const u32x4* __restrict__ v_new,
                                                           u32x4* __restrict__ k_buf, u32x4* __restrict__ v_buf,
                                                           long long k_stride_b, long long k_stride_h, long long k_stride_s,

@@ -886,13 +886,16 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
             for (int g = 0; g < NG; ++g) {
                 uint32_t m = mge[g];
                 if (ord < 2 && m) {
+                    // (a threshold of key 0 - fewer non-zero scores than S - flags the PADDING keys of the row's tail as well:
+                    // they are never placed, the tie rule stops before them, but their index lies past the row - up to 8,191
+                    // for a 300-score row - so the speculative gather clamps it: round 4, a fault on an unmapped page)
                     const int e0 = __builtin_ctz(m);
                     m &= m - 1;
-                    if (ord == 0) id0 = lm_idx[(size_t)b * N + j0 + g * 32 + e0];
-                    else id1 = lm_idx[(size_t)b * N + j0 + g * 32 + e0];
+                    if (ord == 0) id0 = lm_idx[(size_t)b * N + min(j0 + g * 32 + e0, N - 1)];
+                    else id1 = lm_idx[(size_t)b * N + min(j0 + g * 32 + e0, N - 1)];
                     ++ord;
                     if (ord < 2 && m) {
-                        id1 = lm_idx[(size_t)b * N + j0 + g * 32 + __builtin_ctz(m)];
+                        id1 = lm_idx[(size_t)b * N + min(j0 + g * 32 + __builtin_ctz(m), N - 1)];
                         ++ord;
                     }
                 }

@@ -141,7 +141,7 @@ def gram_factorize(k, rank):
 
 class ShadowKVCache_CPU:
     def __init__(self, config, batch_size=1, max_length=32 * 1024, device="cuda:0", dtype=torch.bfloat16,
-                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="svd", v_offload=True, resident_sets=None):
+                 sparse_budget=2048, chunk_size=8, rank=160, svd_mode="auto", v_offload=True, resident_sets=None):
         if dtype != torch.bfloat16:
             raise ValueError("ShadowKVCache_CPU supports bfloat16 only (as the reference's kernels do)")
         self.config = config
@@ -158,8 +158,16 @@ class ShadowKVCache_CPU:
         self.sparse_budget = int(sparse_budget)
         self.chunk_size = chunk_size
         self.rank = rank
-        if svd_mode not in ("svd", "gram"):
-            raise ValueError("svd_mode must be 'svd' (torch.svd, the reference) or 'gram' (K^T K eigendecomposition)")
+        # "auto" (default since round 4): the Gram factorisation when the keys are on a GPU (21.6 ms instead of torch.svd's
+        # 2.1 s per layer at 122K: 0.7 s instead of 68 s per prefill), torch.svd on the CPU (the golden fixtures pin that path
+        # to the reference bit for bit).  SURVEY.md 8c's criterion for this stage is the RECONSTRUCTION U.SV at rtol 1e-2 (an
+        # SVD's signs / rotations are not unique), which tests/test_gpu_build.py asserts for the Gram path against the
+        # reference-pinned factors and against torch.svd at the headline length.  "svd" keeps the reference's call everywhere.
+        if svd_mode is None:
+            svd_mode = "auto"
+        if svd_mode not in ("auto", "svd", "gram"):
+            raise ValueError("svd_mode must be 'auto' (Gram on a GPU, torch.svd on the CPU), 'svd' (torch.svd, the reference's "
+                             "call) or 'gram' (K^T K eigendecomposition)")
         self.svd_mode = svd_mode
         self.local_chunk = 4
         self.outlier_chunk = int((self.sparse_budget // 1024) * 24)
@@ -222,6 +230,8 @@ class ShadowKVCache_CPU:
         self._staged_layer = -1
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
         self._early = None               # speculative early V fetch (enable_early_fetch): per-layer states
+        self._early_request = None       # (early_max, margin) to re-enable with after clear() + a new prefill (H2D)
+        self._pushed = None              # rows the host model's RoPE launch has already pushed (note_rows_pushed)
         # Reference call order (get_value_cache under copy_stream, then get_key_cache, base.py:326-338): with this flag
         # get_value_cache only returns its view and the get_key_cache call that follows for the same layer moves K AND V
         # in ONE launch on its stream (fetch_kv: rebuild tiles and landing workgroups side by side) - nothing runs on
@@ -265,6 +275,19 @@ class ShadowKVCache_CPU:
         self.position_ids.fill_(-1)
         self._slot_age.zero_()
         self._select_ws = None          # sized for the previous landmark count
+        # everything that refers to the previous prompt goes with it.  The early-fetch state is carved for that prompt's
+        # landmark / chunk counts (flag tiles, early_of, staging): it is retired here (a captured step may still point at the
+        # buffers: they stay allocated) and re-created for the next prompt by H2D(), so enable_early_fetch() stays a one-time
+        # call for host code that clears and re-prefills per sample (test/evaluator.py:83 does)
+        if self._early is not None:
+            self._early_request = (self._early["E_request"], self._early["margin"])
+            self._early_retired = getattr(self, "_early_retired", []) + [self._early]
+            self._early = None
+        self._pending_v = None
+        self._early_pub = None
+        self._pushed = None
+        self._last_cos_sin = None
+        self._staged_layer = -1
 
     def H2D(self):
         """Reference: moves U / SV / landmarks / scratch from CPU tensors to the GPU (kv_cache.py:1178-1225).
@@ -275,10 +298,16 @@ class ShadowKVCache_CPU:
             nbytes = lib().skv_select_workspace_bytes(self.block_num, self.num_key_value_groups, n)
             self._select_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             torch.cuda.synchronize(self.device)
+            req = getattr(self, "_early_request", None)
+            if req is not None and self._early is None and self.prefilled_batch == self.batch_size \
+                    and self.early_fetch_supported():
+                self._early_request = None
+                self.enable_early_fetch(early_max=req[0], margin=req[1])
 
     # ------------------------------------------------------------------ prefill-side state builders
     def get_svd(self, new_k_cache, layer_idx):
-        """Rank-r factorisation of the pre-RoPE keys (kv_cache.py:666-737): torch.svd in f32,
+        """Rank-r factorisation of the pre-RoPE keys (kv_cache.py:666-737) in f32: torch.svd (the reference's call) or the
+        Gram-matrix factorisation (gram_factorize; the default for keys on a GPU - see svd_mode in __init__),
         U[:, :, :r] -> bf16, SV = diag(s) V^T stored [bs, kv, D, r] (r-contiguous for the kernels)."""
         kv, D = self.num_key_value_heads, self.head_dim
         if new_k_cache.shape[1] <= 32:   # [bs, kv, seq, D] -> [bs, seq, kv*D]  (same layout test as :683)
@@ -293,7 +322,8 @@ class ShadowKVCache_CPU:
         r = self.rank
         b0 = self.prefilled_batch
         kf = k.float()
-        if self.svd_mode == "svd":
+        mode = self.svd_mode if self.svd_mode != "auto" else ("gram" if kf.is_cuda else "svd")
+        if mode == "svd":
             u, s, v = torch.svd(kf)
             self.U[layer_idx][b0:b0 + bsz].copy_(u[:, :, :r].to(self.dtype))
             sv = torch.matmul(torch.diag_embed(s[:, :r]), v.transpose(1, 2)[:, :r]).to(self.dtype)  # [bs, r, kv*D]
@@ -441,7 +471,7 @@ class ShadowKVCache_CPU:
         if self._select_ws is None:
             self.H2D()
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
-        ea = self._early
+        ea = self._early_state()
         self._early_pub = None
         if ea is not None and (self.lazy_value_fetch or self.fetch_kv_follows):
             # early fetch in the reference's slot order: only when its consumer (fetch_kv - reached through the deferred
@@ -549,7 +579,7 @@ class ShadowKVCache_CPU:
                 ptr(self._temp_v), U.shape[0], self.num_key_value_heads, U.shape[1], self.head_dim,
                 self.rank, self.select_sets, self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0),
                 kbuf.stride(1), kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1))
-        ea = self._early
+        ea = self._early_state()
         if ea is not None and getattr(self, "_early_pub", None) == layer_idx:   # this step's selection published a list
             self._early_pub = None
             check(lib().skv_fetch_kv_early(*args, ptr(ea["states"][layer_idx]), self.num_key_value_groups, ea["n_lm"],
@@ -586,7 +616,7 @@ class ShadowKVCache_CPU:
                     ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
                     self.num_key_value_groups, lm.shape[-2], self.select_sets,
                     self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
-        ea = self._early
+        ea = self._early_state()
         if ea is not None:
             check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
                                                     ea["n_chunks"], ea["E"], ea["margin"], st), "select_chunks_inplace_early")
@@ -605,7 +635,7 @@ class ShadowKVCache_CPU:
                       self.num_key_value_heads, U.shape[1], self.head_dim, self.rank, self.select_sets,
                       self.chunk_size, cos_sin_cache.stride(0), kbuf.stride(0), kbuf.stride(1),
                       kbuf.stride(2), self.sparse_start, 1 if width == 128 else 2, vhost.stride(1))
-        ea = self._early
+        ea = self._early_state()
         if ea is not None:
             check(L.skv_fetch_kv_inplace_early(*fetch_args, ptr(ea["states"][layer_idx]), self.num_key_value_groups, ea["n_lm"],
                                                ea["n_chunks"], ea["E"], st), "fetch_kv_inplace_early")
@@ -643,7 +673,7 @@ class ShadowKVCache_CPU:
         # workgroups, two per CU) + the standalone attention: measured 296 / 451 / 596 / 739 tok/s at bs 2 / 4 / 8 / 24
         # against 292 / 427 / 562 / 687 with the fused launch
         return (self.rank == 160 and self.chunk_size == 8 and self.head_dim == 128 and self.select_sets % 8 == 0
-                and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 64
+                and self.num_key_value_groups in (4, 8) and self.OVERLAP_SPLITS + self.select_sets // 8 <= 128
                 and self.block_num <= 8)
 
     def early_fetch_supported(self):
@@ -651,6 +681,21 @@ class ShadowKVCache_CPU:
         head, V table in pinned host memory."""
         return (self.k_landmark is not None and self.k_landmark.shape[-2] <= 65536 and self.resident_sets <= 1024
                 and self.v_cache_cpu is not None and self.v_cache_cpu.is_pinned())
+
+    def _early_state(self):
+        """The early-fetch state, or None when it is off.  The state is carved for ONE prompt's landmark count, chunk count
+        and block count; the selection launches carve it with the landmark table's shape and the fetch launches with the
+        recorded one, so a state that no longer matches the cache (a re-prefill without clear()) is refused before any
+        launch could read another layout's indices or write past its allocation."""
+        ea = self._early
+        if ea is None:
+            return None
+        n_lm = self.k_landmark.shape[-2] if self.k_landmark is not None else -1
+        if ea["n_lm"] != n_lm or ea["n_chunks"] != self.v_cache_cpu.shape[-2] or ea["blocks"] != self.block_num:
+            raise RuntimeError(f"early-fetch state was built for {ea['n_lm']} landmarks / {ea['n_chunks']} chunks / {ea['blocks']} "
+                               f"blocks, the cache now holds {n_lm} / {self.v_cache_cpu.shape[-2]} / {self.block_num}: call "
+                               "clear() before a new prefill (it retires the state) or enable_early_fetch() again")
+        return ea
 
     @property
     def copy_stream(self):
@@ -674,6 +719,7 @@ class ShadowKVCache_CPU:
             if self._early is not None:      # a captured step may still point at the state buffers: they stay allocated
                 self._early_retired = getattr(self, "_early_retired", []) + [self._early]
             self._early = None
+            self._early_request = None
             return
         if not self.early_fetch_supported():
             raise RuntimeError("early fetch needs the prefilled state with the V table in pinned host memory, at most 65,536 "
@@ -698,7 +744,9 @@ class ShadowKVCache_CPU:
         torch.cuda.synchronize(self.device)
         if self._early is not None:
             self._early_retired = getattr(self, "_early_retired", []) + [self._early]
-        self._early = dict(states=states, E=E, margin=float(margin), n_lm=n_lm, n_chunks=n_chunks, offsets=list(offs))
+        self._early = dict(states=states, E=E, E_request=early_max, margin=float(margin), n_lm=n_lm, n_chunks=n_chunks,
+                           blocks=self.block_num, offsets=list(offs))
+        self._early_request = None
 
     def early_fetch_counts(self, layer_idx):
         """Chunks pulled early per (batch, head) in the last step of this layer (int32 [blocks]); diagnostic, synchronises."""
@@ -710,7 +758,9 @@ class ShadowKVCache_CPU:
 
     def early_fetch_stats(self, layer_idx):
         """(chunks pulled early, of these selected - i.e. read from staging by the fetch launch -, misses) summed over the
-        heads, for the last step of this layer; diagnostic, synchronises."""
+        heads; diagnostic, synchronises.  Valid for the layer launched LAST only (pass num_layers - 1 after a decode step):
+        the miss list (self.offsets) is shared by all layers and rewritten by every layer's selection; the early ids and
+        counts are per layer (early_fetch_counts works for any layer)."""
         if self._early is None:
             return None
         e = self._early
@@ -758,7 +808,7 @@ class ShadowKVCache_CPU:
                     ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
                     self.num_key_value_groups, lm.shape[-2], self.select_sets,
                     self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
-        ea = self._early
+        ea = self._early_state()
         if ea is not None:
             check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
                                                     ea["n_chunks"], ea["E"], ea["margin"], st),
@@ -806,11 +856,12 @@ class ShadowKVCache_CPU:
         the buffer; the reference drops such rows)."""
         return self.sparse_end + self.gen_offset + incoming <= self.k_cache_buffer.shape[-2]
 
-    def note_rows_pushed(self, layer_idx, row, incoming):
+    def note_rows_pushed(self, layer_idx, row, incoming, v_src_ptr=None):
         """The host model's RoPE launch has already written the new token's rotated K and its V into rows [row, row +
         incoming) of this layer's buffers (DecoderLM.apply_rotary_pos_emb); the update_kv_cache call that follows for the
-        same layer and rows does the bookkeeping only."""
-        self._pushed = (layer_idx, row, incoming)
+        same layer and rows does the bookkeeping only - provided it is handed the pushed K view AND the V tensor the push
+        read (v_src_ptr = its data pointer; None: any V is taken to be the pushed one)."""
+        self._pushed = (layer_idx, row, incoming, v_src_ptr)
 
     def update_kv_cache(self, new_k_cache, new_v_cache, layer_idx):
         """Appends the new token's K / V after the sparse region (kv_cache.py:1227-1271); rows past
@@ -819,10 +870,13 @@ class ShadowKVCache_CPU:
         lo = self.sparse_end + self.gen_offset
         lv = self._layer(layer_idx)
         k, v = new_k_cache, new_v_cache
-        pushed, self._pushed = getattr(self, "_pushed", None), None
-        if pushed == (layer_idx, lo, incoming) and k.data_ptr() == lv.kbuf.data_ptr() + lo * self.head_dim * 2:
+        pushed, self._pushed = self._pushed, None
+        if (pushed is not None and pushed[:3] == (layer_idx, lo, incoming)
+                and k.data_ptr() == lv.kbuf.data_ptr() + lo * self.head_dim * 2
+                and (pushed[3] is None or pushed[3] == v.data_ptr())):
             pass                                                # rows already in place (see note_rows_pushed)
         elif (k.is_cuda and k.dtype == torch.bfloat16 and k.shape[-1] == 128 and k.stride(-1) == 1 and v.stride(-1) == 1
+                and v.is_cuda and v.dtype == torch.bfloat16 and v.shape == k.shape
                 and not ((k.stride(0) | k.stride(1) | k.stride(2) | v.stride(0) | v.stride(1) | v.stride(2)) % 8)
                 and not ((k.data_ptr() | v.data_ptr()) % 16)):
             kb = lv.kbuf                                        # one native launch for both buffers

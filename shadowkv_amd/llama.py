@@ -40,6 +40,10 @@ class ModelConfig:
 
 LLAMA_3_1_8B = ModelConfig()
 LLAMA_3_8B_1048K = ModelConfig(name="llama-3-8b-gradient-1048k", rope_theta=3580165449.0)
+# 01-ai/Yi-9B-200K (test/e2e.py:76-94, index.html:240-258; served by models/llama.py): 48 layers, 32 query / 4 KV heads (G = 8
+# with NeoX RoPE), hidden 4096, intermediate 11008, vocabulary 64000
+YI_9B_200K = ModelConfig(name="yi-9b-200k", intermediate_size=11008, num_hidden_layers=48, num_key_value_heads=4,
+                         vocab_size=64000, rms_norm_eps=1e-6, rope_theta=10000000.0)
 GLM_4_9B_1M = ModelConfig(name="glm-4-9b-1m", intermediate_size=13696, num_hidden_layers=40, num_key_value_heads=4,
                           vocab_size=151552, rms_norm_eps=1.5625e-07, rope_theta=10000.0 * 1e4, qkv_bias=True,
                           rope_style="glm")
@@ -128,6 +132,7 @@ class DecoderLM:
                                               dtype=dtype, sparse_budget=sparse_budget, chunk_size=chunk_size,
                                               rank=rank, v_offload=v_offload, resident_sets=resident_sets)
         self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
+        self._sampler_state = {}
 
     def weight_bytes(self):
         n = self.lm_head.numel()   # one embedding row is read per token: not counted
@@ -163,7 +168,12 @@ class DecoderLM:
 
     def pre_attention_compute(self, hidden_states, layer):
         """RMSNorm -> fused QKV projection -> split (llama.py:283-303).  One decode token per sequence takes the native
-        kernels (norm in the GEMV's prologue at bs 1, the rows GEMM for 2..32 sequences); prefill-sized inputs F.linear."""
+        kernels (norm in the GEMV's prologue at bs 1, the rows GEMM for 2..32 sequences); prefill-sized inputs F.linear.
+        ALIASING CONTRACT of the one-token path (pre_attention_compute, apply_rotary_pos_emb, post_attention_compute,
+        layer_compute): results are views of two per-model scratch sets that ALTERNATE per layer - this method flips to the
+        other set - so a returned tensor is valid until the same method has run for the layer after the next one (the
+        reference returns fresh tensors).  Host code that keeps a hidden state or q / k / v across more than one layer, or
+        across steps (hidden-state capture), must clone() it."""
         if hidden_states.shape[1] == 1 and hidden_states.is_cuda:
             sc = self._decode_scratch(hidden_states.shape[0])
             sc["i"] ^= 1                                        # (a new layer: the other buffer set)
@@ -208,7 +218,7 @@ class DecoderLM:
                 kbuf, vbuf = lv.kbuf, lv.vbuf
                 qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, sc["row"], kbuf, vbuf, self.num_heads,
                                                self.num_key_value_heads, q_override=q_over, q_out=cur["q"])
-                c.note_rows_pushed(layer_idx, row, 1)
+                c.note_rows_pushed(layer_idx, row, 1, v_src_ptr=k.data_ptr() + self.num_key_value_heads * self.head_dim * 2)
                 return qr, kbuf[:, :, row:row + 1]
             qr = tensor_op.qkv_rope_update(qkv, self.cos_sin_cache, position_ids, sc["row0"], cur["k"], cur["v"],
                                            self.num_heads, self.num_key_value_heads, q_override=q_over, q_out=cur["q"])
@@ -368,7 +378,8 @@ class DecoderLM:
             row_idx = torch.tensor([row], device=self.device, dtype=torch.long)
             logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table, as_float=False)
             c.note_kv_appended(1)
-        return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k)
+        return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k,
+                                      state=self._sampler_state)   # (draw counters of THIS model)
 
 
 class Llama(DecoderLM):

@@ -229,6 +229,14 @@ def attention_workspace(device, bs, Hq, splits):
     return ws
 
 
+def default_attention_splits(bs, Hkv, rows):
+    """Splits of the standalone attention pass when the caller names none: one workgroup per (kv head, split) to fill the
+    256 CUs (profiles/r02_attn_mfma_probe.txt: 64 splits beat 32 for 4 KV heads), at most 60 (the combine kernel merges up
+    to 62 records); long rows (full-attention baseline: 125 K keys per head) get a split per ~2 K keys whatever the batch,
+    so that every CU holds several workgroups."""
+    return max(1, min(60, max(256 // max(1, bs * Hkv), -(-rows // 2048))))
+
+
 def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, splits=None, out=None, slots=None,
                             select_sets=0, sparse_start=0, resident_sets=0):
     """softmax(q K^T / sqrt(D)) V for q_len == 1 over the first kv_len rows of the cache views.
@@ -251,11 +259,7 @@ def sparse_attention_decode(q, k_cache, v_cache, kv_len=None, kv_len_dev=None, s
     if not q.is_contiguous():
         q = q.contiguous()
     if splits is None:
-        # one workgroup per (kv head, split): fill the 256 CUs (profiles/r02_attn_mfma_probe.txt: 64 splits beat 32 for
-        # 4 KV heads); the combine kernel merges up to 62 records
-        # long rows (full-attention baseline: 125 K keys per head) get a split per ~2 K keys whatever the batch, so that
-        # every CU holds several workgroups
-        splits = max(1, min(60, max(256 // max(1, bs * Hkv), -(-rows // 2048))))
+        splits = default_attention_splits(bs, Hkv, rows)
     ws = attention_workspace(q.device, bs, Hq, splits)
     if out is None:
         out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
@@ -315,25 +319,45 @@ def sample(probs, num_samples=1):
 
 
 _sampler_state = {}
+_sampler_seed = None
 
 
-def sample_token_native(logits, temperature, top_k, top_p, seed=1234):
+def set_sampler_seed(seed):
+    """Seed of the native sampler's counter-based random numbers (None: follow torch.initial_seed(), i.e. what
+    torch.manual_seed(...) last set).  A new seed restarts every draw counter, so `manual_seed(s)` followed by the same calls
+    draws the same tokens."""
+    global _sampler_seed
+    _sampler_seed = None if seed is None else int(seed)
+
+
+def sample_token_native(logits, temperature, top_k, top_p, seed=None, state=None):
     """sample_token in ONE native launch for bf16 logits [bs, V] on the GPU (skv_sample_topk_advance: exact k-th value,
     every logit tied with it kept - the reference's filter -, logit / temperature, nucleus, draw).  Same distribution as
-    the torch pipeline below; the random numbers come from a counter-based hash (seed, draw counter, row), not from
-    torch's generator.  Returns None when the kernel does not take the row (caller falls back)."""
+    the torch pipeline below; the random numbers are NOT torch's generator stream: they come from a counter-based hash of
+    (seed, draw counter, row) with seed = `seed`, else set_sampler_seed(), else torch.initial_seed() (so torch.manual_seed
+    reseeds it), and a draw counter kept per `state` (any dict a caller owns - one per model or generation - default: one
+    per (device, batch size) of the process).  Returns None when the kernel does not take the row (caller falls back)."""
     bs, V = logits.shape
     k = min(top_k, V) if top_k > 0 else V
     if not (logits.is_cuda and logits.dtype == torch.bfloat16 and temperature > 0.0 and 1 <= k <= 64 and V % 8 == 0
             and V <= 4 * 131072 and logits.stride(-1) == 1 and logits.stride(0) % 8 == 0 and logits.data_ptr() % 16 == 0):
         return None
+    if seed is None:
+        seed = _sampler_seed if _sampler_seed is not None else torch.initial_seed()
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     key = (logits.device.index, bs)
-    st = _sampler_state.get(key)
+    holder = _sampler_state if state is None else state
+    st = holder.get(key)
     if st is None:
         dev = logits.device
         st = dict(pos=torch.zeros(bs, 1, dtype=torch.long, device=dev), gen=torch.zeros(1, dtype=torch.long, device=dev),
-                  row=torch.zeros(1, dtype=torch.long, device=dev), kvl=torch.zeros(1, dtype=torch.int32, device=dev))
-        _sampler_state[key] = st
+                  row=torch.zeros(1, dtype=torch.long, device=dev), kvl=torch.zeros(1, dtype=torch.int32, device=dev),
+                  seed=seed)
+        holder[key] = st
+    elif st["seed"] != seed:            # reseeded: the draw counter starts again
+        st["gen"].zero_()
+        st["pos"].zero_()
+        st["seed"] = seed
     token = torch.empty(bs, 1, dtype=torch.long, device=logits.device)
     check(lib().skv_sample_topk_advance(ptr(logits), logits.stride(0), V, bs, k, float(temperature), float(top_p), seed,
                                         ptr(token), ptr(st["pos"]), ptr(st["gen"]), ptr(st["row"]), ptr(st["kvl"]), 0, 0, 1, 1,
@@ -341,11 +365,13 @@ def sample_token_native(logits, temperature, top_k, top_p, seed=1234):
     return token
 
 
-def sample_token(logits, temperature=0, top_k=50, top_p=0.9):
+def sample_token(logits, temperature=0, top_k=50, top_p=0.9, state=None):
+    """tensor_op.py:291-297.  bf16 logits on the GPU take the native sampler, whose random numbers are not torch's generator
+    stream (see sample_token_native: seeded from torch.initial_seed() / set_sampler_seed, draw counter per `state`)."""
     if temperature == 0.0:
         return logits.argmax(dim=-1, keepdim=True)
     if logits.dtype == torch.bfloat16 and logits.is_cuda:     # the lm_head's own output: one native launch
-        tok = sample_token_native(logits, temperature, top_k, top_p)
+        tok = sample_token_native(logits, temperature, top_k, top_p, state=state)
         if tok is not None:
             return tok
         logits = logits.float()

@@ -77,7 +77,7 @@ def test_numa_queries_do_not_raise():
     n = bench.numa_node_of_address(t.data_ptr())
     assert n is None or n >= 0
     p = bench.process_numa_node()
-    assert p is None or p >= 0
+    assert p is not None and p >= 0           # (round 3: null on the driver's box - Python 3.10 has no os.sched_getcpu)
     c = bench.physical_cores()
     assert c is None or 1 <= c <= os.cpu_count()
 
@@ -95,3 +95,110 @@ def test_replica_aggregation_two_ranks():
 def test_aggregate_throughput_single():
     import bench
     assert bench.aggregate_throughput([64], [0.5]) == 128.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.main()'s own control flow on two ranks (round 4): the rank gating (only rank 0 measures the extras and prints),
+# the barrier / MAX all-reduce inside run_decode's timed region, the per-rank gather, the final barrier - over gloo with
+# a stub model in place of the GPU work (the real main(), the real argument parsing, the real JSON assembly).
+# ----------------------------------------------------------------------------------------------------------------------
+def _stub_bench(bench, rank):
+    import types
+    cache = types.SimpleNamespace(resident_sets=256, select_sets=256, block_num=8, _early=None, rank=160, sparse_end=2496,
+                                  k_landmark=torch.zeros(1, 1, 8, 16, 128), v_cache_cpu=torch.zeros(4, 1024, dtype=torch.bfloat16))
+    cfg = types.SimpleNamespace(name="stub-llama", vocab_size=128)
+    model = types.SimpleNamespace(batch_size=1, kv_cache=cache, num_layers=2, attn_mode="shadowkv_cpu", cfg=cfg)
+    calls = dict(build=0, decode=0, score=0)
+
+    def build_model(workload, args, rank_, dev, **kw):
+        calls["build"] += 1
+        return model, cfg, 124928, 2048, 1.5 + rank_
+
+    def run_decode(model_, args, ctx, steps, warmup, walk_step, seed, world=1, pin_hit=None):
+        # the timed region's collectives exactly as bench.run_decode issues them (barrier, barrier, MAX of the elapsed time)
+        calls["decode"] += 1
+        dist.barrier()
+        elapsed_local = 0.5 * (rank + 1)                 # rank 1 is the slow replica
+        dist.barrier()
+        t = torch.tensor([elapsed_local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return dict(value=bench.aggregate_throughput([steps] * world, [float(t)]), ms_per_step=float(t) / steps * 1e3,
+                    hit_rate=0.6 + 0.1 * rank, mode=args.mode, slack_ring=False, elapsed_local=elapsed_local, steps=steps)
+
+    def measure_score_kernel(model_, iters=3):
+        calls["score"] += 1
+        return dict(kernel="stub", us_per_launch=8.0, algorithmic_bytes=32_000_000, gbs=4000.0)
+
+    bench.DIST_BACKEND = "gloo"
+    bench.setup_device = lambda local_rank: ("cpu", local_rank)
+    bench.build_model, bench.run_decode, bench.measure_score_kernel = build_model, run_decode, measure_score_kernel
+    return calls
+
+
+def _worker_main(rank, world, port, out):
+    import contextlib
+    import io
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import bench
+    calls = _stub_bench(bench, rank)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "10", "--warmup", "2"])
+    # main() has destroyed the process group behind its final barrier: every rank got here
+    out[rank] = (buf.getvalue(), dict(calls), dist.is_initialized())
+
+
+def test_bench_main_on_two_ranks_prints_one_line_on_rank_zero():
+    import json
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_main, args=(2, port, out), nprocs=2, join=True)
+        out = dict(out)
+    (text0, calls0, init0), (text1, calls1, init1) = out[0], out[1]
+    assert text1 == "" and calls1 == dict(build=1, decode=1, score=0)       # rank 1: decodes, prints and measures nothing else
+    assert calls0 == dict(build=1, decode=1, score=1) and not init0 and not init1
+    lines = [l for l in text0.splitlines() if l.strip()]
+    assert len(lines) == 1, text0                                           # exactly ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 10 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert rec["metric"].startswith("decode tokens/sec @122K ctx") and rec["unit"] == "tokens/s" and rec["vs_baseline"] is None
+    assert rec["value"] == 2 * 10 / 1.0 and rec["ms_per_step"] == 100.0     # 2 replicas x 10 tokens / the slowest rank's 1.0 s
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
+    assert [r["tokens_per_s"] for r in rec["per_rank"]] == [20.0, 10.0]     # each rank's OWN rate
+    assert rec["per_rank"][1]["state_build_s"] == 2.5 and rec["per_rank"][1]["chunk_hit_rate"] == 0.7
+    assert "replicas x2" in rec["config"]["parallelism"] and rec["roofline"]["frac"] == 0.5
+    for key in ("cpu_baseline", "secondary", "batched", "hit_rate_sweep"):  # N = 1 extras are not run at N > 1
+        assert key not in rec
+
+
+def test_bench_main_refuses_gpus_without_a_launcher():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "torch.distributed.run --nproc-per-node 2" in r.stderr
+
+
+def test_process_numa_node_falls_back_to_the_node_cpulists(tmp_path):
+    """The driver's N = 1 box in round 3 reported process_numa_node null: its /sys/devices/system/cpu/cpuN has no nodeM link.
+    The fallback scans /sys/devices/system/node/node*/cpulist; a tree with neither reports node 0 for an online CPU."""
+    import bench
+    cpu = bench.current_cpu()
+    assert cpu is not None and cpu in os.sched_getaffinity(0)
+    bench.current_cpu = lambda: cpu                                       # (the scheduler may move the process between calls)
+    root = tmp_path / "system"
+    (root / "cpu" / f"cpu{cpu}").mkdir(parents=True)
+    for n, lst in ((0, f"{cpu + 1}-{cpu + 3}"), (3, f"0-{cpu}" if cpu else "0"), (10, f"{cpu + 4}")):
+        (root / "node" / f"node{n}").mkdir(parents=True)
+        (root / "node" / f"node{n}" / "cpulist").write_text(lst + "\n")
+    assert bench.process_numa_node(str(root)) == 3
+    (root / "cpu" / f"cpu{cpu}" / "node7").mkdir()                        # the direct link wins when it exists
+    assert bench.process_numa_node(str(root)) == 7
+    bare = tmp_path / "bare"
+    (bare / "cpu" / f"cpu{cpu}").mkdir(parents=True)
+    (bare / "cpu" / "online").write_text(f"0-{cpu + 8}\n")
+    assert bench.process_numa_node(str(bare)) == 0
+    assert bench.process_numa_node(str(tmp_path / "missing")) is None
+    assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}

@@ -174,3 +174,35 @@ def test_gram_factorisation_at_headline_length_and_rank_deficient_keys():
     k3 = torch.zeros(1, 4096, H, device=DEV)                             # all-zero keys: zero factors, not NaN
     u3, sv3 = gram_factorize(k3, r)
     assert float(u3.abs().max()) == 0.0 and float(sv3.abs().max()) == 0.0
+
+
+def test_default_factorisation_on_a_gpu_is_the_gram_path():
+    """Round 4: get_svd's default (svd_mode='auto') takes the Gram factorisation for keys on a GPU and torch.svd on the CPU;
+    'svd' stays selectable.  The default's factors are the Gram path's bit for bit, and its rank-160 reconstruction meets
+    SURVEY.md 8c's criterion (rtol 1e-2 of the RMS key value) against the reference's own call on the same keys
+    (/root/reference/models/kv_cache.py:700-733)."""
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    case = "llama_small"
+    c, inp = G.CASES[case], G.make_inputs(case)
+    caches = {}
+    for mode in ("auto", "gram", "svd"):
+        cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=DEV, dtype=torch.bfloat16,
+                                  sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], svd_mode=mode)
+        cache.get_svd(inp["k_pre"].to(DEV), 0)
+        caches[mode] = cache
+    torch.cuda.synchronize()
+    assert ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=DEV).svd_mode == "auto"
+    assert_bits_equal(caches["auto"].U.cpu(), caches["gram"].U.cpu())
+    assert_bits_equal(caches["auto"].SV.cpu(), caches["gram"].SV.cpu())
+    k = inp["k_pre"].float()
+    scale = k.pow(2).mean().sqrt()
+    rec_d, rec_s = _recon(caches["auto"].U[0], caches["auto"].SV[0]).cpu(), _recon(caches["svd"].U[0], caches["svd"].SV[0]).cpu()
+    assert float((rec_d - rec_s).pow(2).mean().sqrt() / scale) < 1e-2
+    # the CPU default is still the reference's torch.svd (the fixtures pin it bit for bit: tests/test_kv_cache_cpu.py)
+    cpu = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", sparse_budget=c["budget"],
+                            chunk_size=c["chunk"], rank=c["rank"])
+    ref = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", sparse_budget=c["budget"],
+                            chunk_size=c["chunk"], rank=c["rank"], svd_mode="svd")
+    cpu.get_svd(inp["k_pre"], 0); ref.get_svd(inp["k_pre"], 0)
+    assert_bits_equal(cpu.U, ref.U)
+    assert_bits_equal(cpu.SV, ref.SV)

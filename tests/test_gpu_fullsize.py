@@ -1,41 +1,67 @@
-"""GPU, BASELINE.json sizes (Llama-3.1-8B shapes, 124,928-token context, budget 2048, rank 160; 2 layers to keep the
-run short): size-independent properties of the decode path after several captured steps - the oracle cannot follow at
+"""GPU, BASELINE.json sizes, on the path the headline runs by default (bench.py: in-place layout, attention inside the fetch
+launch, hipGraph, SPECULATIVE EARLY V FETCH ON with the default chunks per head): Llama-3.1-8B shapes at 124,928 tokens
+(config 1: 61 scan tiles per head, E = 28) and GLM-4-9B shapes at 204,800 tokens (config 3: 4 KV heads x 8 query heads, GLM
+RoPE, 100 scan tiles per head, E = 64), budget 2048, rank 160, 2 layers to keep the run short.  The oracle cannot follow at
 this size in seconds, so the checks are invariants the domain offers:
-  * every slot of the sparse region holds exactly the V chunk its position_ids entry names (bytes from the host table)
+  * every slot of the sparse region holds exactly the V chunk its position_ids entry names (bytes from the host table:
+    kv_cache.py:1081-1095 / copy.cuh:785-846 move byte-exact rows) - also for the chunks the early fetch staged in HBM
   * its K rows equal RoPE(U[rows] . SV^T) recomputed with PyTorch for the same ids (tolerance of the MFMA order)
   * position_ids of a head are distinct, in range, and none is an outlier chunk (all are landmark ids)
   * the K rebuild is homogeneous: scaling SV by 2 scales every rebuilt key by exactly 2 (bf16 scaling is exact and
     commutes with every rounding point), bit for bit, at full U size (64-bit row offsets)
+  * with the early fetch on, tokens, position_ids, hit counts and both caches are bit-equal to the SAME captured steps
+    without it, and chunks are pulled early on every layer in every step after the first
 """
-import math
-
 import pytest
 import torch
 
+from util import rope_pair_bound
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-CTX = 124928
+SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928), "glm4_200k": ("GLM_4_9B_1M", 204800)}
+REPLAYS = 6
+_RUNS = {}
 
 
-@pytest.fixture(scope="module")
-def decoded():
+def _run(shape, early):
+    """One model of `shape` decoded for 2 eager warm-up steps + REPLAYS captured steps; cached per (shape, early) so that
+    the comparison test reuses the fixtures' runs.  Returns (model, tokens of the replays, chunks pulled early per replay
+    and layer or None)."""
+    key = (shape, early)
+    if key in _RUNS:
+        return _RUNS[key]
     from shadowkv_amd import llama
-    m = llama.DecoderLM(cfg=llama.LLAMA_3_1_8B, batch_size=1, max_length=CTX, device=DEV, sparse_budget=2048, rank=160,
+    cfg_name, ctx = SHAPES[shape]
+    m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=2048, rank=160,
                         chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
-    llama.build_synthetic_context(m, CTX, seed=11)
+    llama.build_synthetic_context(m, ctx, seed=11)
+    if early:
+        m.kv_cache.enable_early_fetch()                 # the default E of the shape: what bench.py's headline runs with
     table = llama.make_walk_table(m, 12, seed=5)
     dec = llama.GraphDecoder(m, temperature=0.6, walk_table=table)
     dec.token.copy_(torch.tensor([[7]], device=DEV))
     dec.capture()
-    for _ in range(6):
-        dec.step()
+    tokens, pulled = [], []
+    for _ in range(REPLAYS):
+        tokens.append(int(dec.step()[0, 0]))            # (reads the token back: one sync per step, as bench.py does)
+        if early:
+            pulled.append([int(m.kv_cache.early_fetch_counts(l).sum()) for l in range(m.num_layers)])
     torch.cuda.synchronize()
-    return m
+    _RUNS[key] = (m, tokens, pulled if early else None)
+    return _RUNS[key]
+
+
+@pytest.fixture(scope="module", params=[("llama31_122k", False), ("llama31_122k", True), ("glm4_200k", True)],
+                ids=["llama31_122k-plain", "llama31_122k-early28", "glm4_200k-early64"])
+def decoded(request):
+    return _run(*request.param)[0]
 
 
 def test_sparse_region_holds_the_chunks_its_ids_name(decoded):
     m = decoded
     c = m.kv_cache
+    glm = m.cfg.rope_style == "glm"
     C, D, S = c.chunk_size, c.head_dim, c.select_sets
     assert (c.sparse_start, c.sparse_end, S) == (448, 2496, 256)
     for l in range(m.num_layers):
@@ -51,19 +77,26 @@ def test_sparse_region_holds_the_chunks_its_ids_name(decoded):
             tok = (ids.unsqueeze(-1) * C + torch.arange(C, device=DEV)).view(-1)
             k_pre = (c.U[l][0][tok].float() @ c.SV[l][0, h].float().t()).bfloat16()   # [S*C, D]
             cs = m.cos_sin_cache[tok].float()
-            cos, sin = cs[:, :64], cs[:, 64:]
-            x1, x2 = k_pre[:, :64].float(), k_pre[:, 64:].float()
-            want_k = torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
+            if glm:       # interleaved pairs (2t, 2t+1) of dims 0..63 with cos = cs[t], sin = cs[32 + t]; 64..127 copied
+                cos, sin = cs[:, :32], cs[:, 32:]
+                xe, xo = k_pre[:, 0:64:2].float(), k_pre[:, 1:64:2].float()
+                rot = torch.stack((xe * cos - xo * sin, xo * cos + xe * sin), dim=-1).flatten(-2)
+                want_k = torch.cat((rot, k_pre[:, 64:].float()), dim=-1)
+            else:
+                cos, sin = cs[:, :64], cs[:, 64:]
+                x1, x2 = k_pre[:, :64].float(), k_pre[:, 64:].float()
+                want_k = torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
             got_k = c.k_cache_buffer[l][0, h, c.sparse_start:c.sparse_end].float()
-            bound = 2.0 ** -6 * torch.cat((x1.abs() + x2.abs(),) * 2, dim=-1) + 1e-3
+            bound = rope_pair_bound(k_pre, glm).to(DEV) + 1e-3
             assert bool(((got_k - want_k).abs() <= bound).all()), (l, h, float(((got_k - want_k).abs() - bound).max()))
 
 
 def test_generated_rows_and_counters(decoded):
     m = decoded
     c = m.kv_cache
-    n = 8                                                                  # 2 eager warm-up steps + 6 replays
-    assert c.kv_offset == CTX + n and c.gen_offset == n
+    n = 2 + REPLAYS                                                        # 2 eager warm-up steps + the replays
+    ctx = SHAPES["glm4_200k" if m.cfg.rope_style == "glm" else "llama31_122k"][1]
+    assert c.kv_offset == ctx + n and c.gen_offset == n
     for l in range(m.num_layers):
         for buf in (c.k_cache_buffer, c.v_cache_buffer):
             gen = buf[l][0, :, c.sparse_end:c.sparse_end + n].float()
@@ -88,3 +121,27 @@ def test_rebuild_is_homogeneous_at_full_size(decoded):
     torch.cuda.synchronize()
     assert float(out[0].abs().sum()) > 0
     assert torch.equal(out[1], 2.0 * out[0])
+
+
+@pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k"])
+def test_early_fetch_changes_no_bit_at_full_size(shape):
+    """The headline's default path against the same captured steps without the early fetch, at the size the headline runs
+    it (61 / 100 flag tiles per head, early_of over 15,616 / 25,600 chunks): sampled tokens, slot -> chunk map, hit counts
+    and both caches bit for bit; the prediction fires on every layer in every step after the first (the two eager warm-up
+    steps precede the replays, so every replay has thresholds)."""
+    me, tok_e, pulled = _run(shape, True)
+    mp, tok_p, _ = _run(shape, False)
+    ce, cp = me.kv_cache, mp.kv_cache
+    E = ce._early["E"]
+    assert E == (64 if shape == "glm4_200k" else 28)
+    assert ce.k_landmark.shape[-2] == (25544 if shape == "glm4_200k" else 15560)
+    assert tok_e == tok_p, (tok_e, tok_p)
+    assert torch.equal(ce.position_ids, cp.position_ids)
+    assert torch.equal(ce._cnts_layers, cp._cnts_layers)
+    assert torch.equal(ce.v_cache_buffer.view(torch.int16), cp.v_cache_buffer.view(torch.int16))
+    assert torch.equal(ce.k_cache_buffer.view(torch.int16), cp.k_cache_buffer.view(torch.int16))
+    assert len(pulled) == REPLAYS
+    for step, per_layer in enumerate(pulled):
+        assert all(0 < n <= E * ce.block_num for n in per_layer), (step, per_layer)
+    misses = ce.block_num * ce.select_sets * me.num_layers - int(ce._cnts_layers.sum())
+    assert misses > 0, "the walk produced no miss in the last step: nothing was fetched"

@@ -7,7 +7,7 @@ import torch
 
 import gen_inputs as G
 import oracle
-from util import attention_tolerance, record_attention_parity, ALPHA, assert_bits_equal, ulp_diff_bf16, rope_pair_bound, record_parity, REBUILD_FLIP_BOUND
+from util import attention_tolerance, check_attention, standalone_pass_labels, overlapped_pass_labels, ALPHA, assert_bits_equal, ulp_diff_bf16, rope_pair_bound, record_parity, REBUILD_FLIP_BOUND
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -144,13 +144,11 @@ def test_decode_steps_match_oracle(case):
         kbuf.copy_(kgpu)                                                # keep the mirror on the device's K bits
         # returned views: [:, :, :sparse_end + gen]
         assert k_view.shape[2] == cache.sparse_end + t + 1 and v_view.shape[2] == k_view.shape[2]
-        _, a32 = oracle.sparse_attention(q.view(1, Hq, D).contiguous(), kgpu.unsqueeze(0).contiguous(),
-                                         vbuf.unsqueeze(0).contiguous(), k_view.shape[2], 1 / math.sqrt(D))
-        _, aabs = oracle.sparse_attention(q.view(1, Hq, D).contiguous(), kgpu.unsqueeze(0).contiguous(),
-                                          vbuf.abs().unsqueeze(0).contiguous(), k_view.shape[2], 1 / math.sqrt(D))
-        got = attn.view(1, Hq, D).cpu().float()
-        tol = attention_tolerance(a32, aabs)          # (standalone pass: bf16 softmax weights on the matrix pipe)
-        assert bool(((got - a32).abs() <= tol).all()), f"step {t}: attention max err {float((got - a32).abs().max())}"
+        # (standalone pass: bf16 softmax weights on the matrix pipe - the oracle rounds them at the same points)
+        n_att = k_view.shape[2]
+        check_attention(f"test_decode_steps_match_oracle[{case}] step {t}", attn.view(1, Hq, D).cpu().float(),
+                        q.view(1, Hq, D).contiguous(), kgpu.unsqueeze(0).contiguous(), vbuf.unsqueeze(0).contiguous(), n_att,
+                        1 / math.sqrt(D), standalone_pass_labels(1, Hq, kv, n_att, tensor_op.default_attention_splits(1, kv, n_att)))
     assert max(hit_rates) > 0.0   # the random-walk queries do re-select resident chunks
 
 
@@ -291,29 +289,37 @@ def test_overlapped_attention_equals_fetch_then_attend(case):
         assert o_new.shape == o_ref.shape
         # both HIP paths against the oracle's f32 output at the north-star bound (1e-3 relative + half a bf16 ulp of the
         # output rounding), the bound of the standalone kernel's test
-        _, w32 = oracle.sparse_attention(qd.cpu().view(1, Hq, D), a.k_cache_buffer[0].cpu(), a.v_cache_buffer[0].cpu(),
-                                         rows, 1.0 / math.sqrt(D))
-        _, wabs = oracle.sparse_attention(qd.cpu().view(1, Hq, D), a.k_cache_buffer[0].cpu(), a.v_cache_buffer[0].cpu().abs(),
-                                          rows, 1.0 / math.sqrt(D))
-        # (both paths round the softmax weights to bf16 for the matrix pipe: the standalone pass all of them, the overlapped
-        # path those of the miss tiles)
-        for name, o, tol in (("overlapped", o_new, attention_tolerance(w32, wabs)), ("fetch-then-attend", o_ref, attention_tolerance(w32, wabs))):
-            err = (o.cpu().float().view(1, Hq, D) - w32).abs()
-            assert bool((err <= tol).all()), f"step {t} {name}: attention exceeds the bound by {float((err - tol).max())}"
+        # (both paths round softmax weights to bf16 for the matrix pipe: the standalone pass all of them against its waves'
+        # running maxima, the overlapped path those of the miss tiles against the tile maximum - each has its own oracle labels)
+        kc, vc = a.k_cache_buffer[0].cpu(), a.v_cache_buffer[0].cpu()
+        buf_rows = kc.shape[2]
+        for name, o, labels in (("overlapped", o_new, overlapped_pass_labels(b, rows)),
+                                ("fetch-then-attend", o_ref, standalone_pass_labels(1, Hq, kv, rows, tensor_op.default_attention_splits(1, kv, buf_rows)))):
+            check_attention(f"test_overlapped_attention_equals_fetch_then_attend[{case}] step {t} {name}",
+                            o.cpu().float().view(1, Hq, D), qd.cpu().view(1, Hq, D), kc, vc, rows, 1.0 / math.sqrt(D), labels)
 
 
-def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None):
+def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None, max_length=None):
     """ShadowKVCache_CPU with the headline layout (budget 2,048 -> S = 256, 48 outlier chunks, sparse region rows
     [448, 2496), 96 generated rows) over an L-token synthetic context whose keys are exactly rank 160."""
-    from shadowkv_amd import llama, tensor_op
+    from shadowkv_amd import llama
     from shadowkv_amd.kv_cache import ShadowKVCache_CPU
     mc = llama.ModelConfig(num_hidden_layers=1, num_key_value_heads=kv_heads, rope_style="glm" if glm else "neox",
                            rope_theta=10000.0 if glm else 500000.0)
-    cache = ShadowKVCache_CPU(mc, batch_size=1, max_length=L, device=DEV, dtype=torch.bfloat16, sparse_budget=2048,
+    cache = ShadowKVCache_CPU(mc, batch_size=1, max_length=max_length or L, device=DEV, dtype=torch.bfloat16, sparse_budget=2048,
                               chunk_size=8, rank=160, resident_sets=resident_sets)
+    cs, g = _headline_prefill(cache, L, seed)
+    return cache, cs, g
+
+
+def _headline_prefill(cache, L, seed):
+    """Prefills `cache` (one layer) with an L-token synthetic context (L <= cache.max_length); returns (cos_sin, generator)."""
+    from shadowkv_amd import llama, tensor_op
+    mc, kv_heads = cache.config, cache.num_key_value_heads
+    glm = mc.rope_style == "glm"
     g = torch.Generator(device=DEV).manual_seed(seed)
     D, r = 128, 160
-    cs = llama.build_cos_sin_cache(mc, L + 256, torch.device(DEV), torch.bfloat16)
+    cs = llama.build_cos_sin_cache(mc, cache.max_length + 256, torch.device(DEV), torch.bfloat16)
     U = torch.randn(1, L, r, device=DEV, generator=g).bfloat16()
     SV = (torch.randn(1, kv_heads, D, r, device=DEV, generator=g) / math.sqrt(r)).bfloat16()
     cache.U = U.unsqueeze(0).contiguous(); cache.SV = SV.unsqueeze(0).contiguous()
@@ -330,7 +336,7 @@ def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None):
     q_last = (torch.randn(1, 32, 1, D, device=DEV, generator=g) * 1.5).bfloat16()
     cache.prefill_kv_cache(v, 0, k_roped, q_last)
     cache.H2D()
-    return cache, cs, g
+    return cs, g
 
 
 @pytest.mark.parametrize("kv_heads,glm,hit,ctx", [(8, False, 0.67, 8192), (8, False, 0.0, 8192), (8, False, 1.0, 8192),
@@ -398,19 +404,22 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     bound = rope_pair_bound(pre[0], glm)
     assert bool((kd <= bound).all()), f"K rows exceed the bound by {float((kd - bound).max())}"
     # attention: F32 oracle over the device's own K / V bytes
-    _, a32 = oracle.sparse_attention(q.cpu().view(1, Hq, D).contiguous(), kbuf, vbuf, kv_len, 1 / math.sqrt(D))
-    _, aabs = oracle.sparse_attention(q.cpu().view(1, Hq, D).contiguous(), kbuf, vbuf.abs(), kv_len, 1 / math.sqrt(D))
-    got = out.view(1, Hq, D).cpu().float()
-    tol = attention_tolerance(a32, aabs)       # (the miss tiles' P.V runs on the MFMA with bf16 weights, like flash-attn's)
-    record_attention_parity(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}]", (got - a32).abs(), a32, aabs)
-    assert bool(((got - a32).abs() <= tol).all()), f"attention exceeds the bound by {float(((got - a32).abs() - tol).max())}"
+    # (the miss tiles' P.V runs on the MFMA with bf16 weights, like flash-attn's: the oracle rounds the same weights against
+    # the same tile maxima, from the slots the selection assigned)
+    qc = q.cpu().view(1, Hq, D).contiguous()
+    a32 = check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}]",
+                          out.view(1, Hq, D).cpu().float(), qc, kbuf, vbuf, kv_len, 1 / math.sqrt(D), overlapped_pass_labels(cache, kv_len))
+    _, aabs = oracle.sparse_attention(qc, kbuf, vbuf.abs(), kv_len, 1 / math.sqrt(D))
+    tol = attention_tolerance(a32, aabs)
     # kv_len from device memory (the state is now all hits: same rows, another split of the f32 sums); a host kv_len
     # past the buffer is refused
     kvd = torch.tensor([kv_len], dtype=torch.int32, device=DEV)
     out2 = cache.select_fetch_attend_inplace(0, q, cs, kv_len=0, kv_len_dev=kvd)
     torch.cuda.synchronize()
     assert cache.cnts.cpu().tolist() == [S] * kv_heads
-    assert bool(((out2.view(1, Hq, D).cpu().float() - a32).abs() <= tol).all()), "kv_len on the device"
+    check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}] all hits",
+                    out2.view(1, Hq, D).cpu().float(), qc, kbuf, vbuf, kv_len, 1 / math.sqrt(D), overlapped_pass_labels(cache, kv_len))
+    assert int((overlapped_pass_labels(cache, kv_len)[0] >= 0).sum()) == 0      # (no miss tile: every weight stays f32)
     with pytest.raises(ValueError):
         cache.select_fetch_attend_inplace(0, q, cs, kv_len=2593)
 
@@ -475,11 +484,23 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
                 return torch.cat([buf[0][:, :c.sparse_start], sel_rows, buf[0][:, c.sparse_end:c.sparse_end + gen]],
                                  dim=1).unsqueeze(0).contiguous()
             kview, vview = view_of(kb), view_of(vb)
-            _, a32 = oracle.sparse_attention(q.cpu().view(1, Hq, D).contiguous(), kview, vview, kview.shape[2], 1 / math.sqrt(D))
-            _, aabs = oracle.sparse_attention(q.cpu().view(1, Hq, D).contiguous(), kview, vview.abs(), kview.shape[2], 1 / math.sqrt(D))
-            tol = attention_tolerance(a32, aabs)
-            err = (o.view(1, Hq, D).cpu().float() - a32).abs()
-            assert bool((err <= tol).all()), f"step {step}, {name}: attention exceeds the bound by {float((err - tol).max())}"
+            n_att = kview.shape[2]
+            if overlap:          # miss tiles (virtual slots j >= cnt, tile j // 8) round their weights against the tile maximum
+                cn = c.cnts.cpu()
+                grp = torch.full((1, kv_heads, n_att), -1, dtype=torch.int32)
+                for h in range(kv_heads):
+                    j = torch.arange(int(cn[h]), S)
+                    r = (c.sparse_start + j.unsqueeze(-1) * C + torch.arange(C)).view(-1)
+                    grp[0, h, r] = (j // 8).to(torch.int32).repeat_interleave(C)
+                labels = (grp, torch.zeros_like(grp))
+            elif c.resident_sets != S:
+                labels = None    # standalone pass over a slot list: the VALU body, f32 weights
+            else:                # standalone all-MFMA pass over the buffer's own row order
+                kview, vview = kb[:, :, :c.sparse_end + gen].contiguous(), vb[:, :, :c.sparse_end + gen].contiguous()
+                n_att = kview.shape[2]
+                labels = standalone_pass_labels(1, Hq, kv_heads, n_att, tensor_op.default_attention_splits(1, kv_heads, kb.shape[2]))
+            check_attention(f"test_resident_set_of_512_chunks[kv{kv_heads}-glm{int(glm)}-overlap{int(overlap)}] step {step} {name}",
+                            o.view(1, Hq, D).cpu().float(), q.cpu().view(1, Hq, D).contiguous(), kview, vview, n_att, 1 / math.sqrt(D), labels)
     assert more_hits > 0, "the larger resident set never produced an extra hit"
     with pytest.raises(RuntimeError):
         big.get_retrieval_position_ids(0, q)
@@ -579,3 +600,48 @@ def test_early_fetch_with_thresholds_that_jump_changes_no_selection(kv_heads, gl
         assert torch.equal(ca.position_ids, cb.position_ids), (step, scale)
         assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), (step, scale)
     assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16))
+
+
+@pytest.mark.parametrize("first,second", [(12288, 16384), (16384, 10240)])
+def test_early_fetch_survives_clear_and_a_prompt_of_another_length(first, second):
+    """clear() + a new prefill with the early fetch enabled (the state is carved for one prompt's landmark and chunk
+    counts; the reference's evaluation loop clears and re-prefills per sample, test/evaluator.py:83).  clear() retires the state,
+    H2D() after the next prefill re-creates it for the new landmark count - also when that count grows past a 256-slot tile
+    boundary -, and the steps of the second prompt equal, bit for bit, those of a cache that never had the early fetch; a state
+    that does not match the cache is refused before any launch."""
+    ca, cs, g = _headline_cache(8, False, L=first, seed=41, max_length=16384)
+    cb, _, _ = _headline_cache(8, False, L=first, seed=41, max_length=16384)
+    ca.enable_early_fetch(early_max=24)
+    n_lm_first = ca._early["n_lm"]
+    kv_len = ca.sparse_end + 2
+
+    def steps(n, q):
+        pulled = 0
+        for step in range(n):
+            q = (q.float() + 0.25 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+            oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+            ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+            torch.cuda.synchronize()
+            pulled += int(ca.early_fetch_counts(0).sum())
+            assert torch.equal(ca.cnts, cb.cnts) and torch.equal(ca.offsets, cb.offsets), step
+            assert torch.equal(ca.position_ids, cb.position_ids), step
+            assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), step
+            assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16)), step
+            assert torch.equal(ca.k_cache_buffer.view(torch.int16), cb.k_cache_buffer.view(torch.int16)), step
+        return pulled
+
+    q0 = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
+    assert steps(3, q0) > 0
+    ca.clear(); cb.clear()
+    assert ca._early is None and ca._early_request == (24, 0.0) and ca._pending_v is None and ca._pushed is None
+    _headline_prefill(ca, second, seed=43)
+    _, g = _headline_prefill(cb, second, seed=43)
+    assert ca._early is not None and ca._early["E"] == 24 and ca._early["n_lm"] == ca.k_landmark.shape[-2] != n_lm_first
+    assert steps(4, q0) > 0, "the prediction never fired on the second prompt"
+    # a state built for another landmark count is refused (a new prefill WITHOUT clear() would leave one behind)
+    ca._early["n_lm"] = n_lm_first
+    with pytest.raises(RuntimeError, match="early-fetch state was built for"):
+        ca.select_fetch_attend_inplace(0, q0, cs, kv_len=kv_len)
+    ca._early["n_lm"] = ca.k_landmark.shape[-2]
+    ca.enable_early_fetch(0)
+    assert ca._early is None and ca._early_request is None
