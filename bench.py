@@ -748,6 +748,7 @@ def main(argv=None):
     ap.add_argument("--no-batched", action="store_true", help="skip the bs 8 / bs 24 lines (the reference's published regime)")
     ap.add_argument("--no-pair", action="store_true", help="skip the e2e-style full-attention / ShadowKV pair")
     ap.add_argument("--batched", default="8,24", help="batch sizes of the `batched` entries of the default run")
+    ap.add_argument("--no-batched-resident", action="store_true", help="skip the 512-resident-slot run of every `batched` entry")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -908,13 +909,17 @@ def main(argv=None):
         if detail and not args.no_secondary and args.workload == "llama31_122k" and bs == 1 and args.layers is None:
             import gc
             sec = []
-            for wl in ("llama3_1048k_131072", "glm4_200k"):       # BASELINE.json configs 2 and 3, short runs
+            # BASELINE.json configs 2 and 3, then the reference's other regimes (test/e2e.py:35-116: budget 4096 at 244K, budget
+            # 1024 at 60K, and Yi-9B-200K = G 8 with NeoX RoPE); short runs
+            for wl in ("llama3_1048k_131072", "glm4_200k", "llama31_244k_b4096", "llama31_60k_b1024", "yi9b_122k"):
                 model = cache = None
                 gc.collect(); torch.cuda.empty_cache()
                 model, cfg2, ctx2, budget2, tb = build_model(wl, args, rank, dev)
                 r = run_decode(model, args, ctx2, 24, 4, args.walk_step, seed=99 + rank)
                 rf = measure_score_kernel(model)          # the landmark scan of THIS workload's shape against the HBM roof
-                sec.append(dict(workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
+                sec.append(dict(name=wl, workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
+                                path="in-place layout, attention inside the fetch launch" if model.kv_cache.can_overlap_attention() else "plain fetch launch + standalone attention",
+                                early_fetch_chunks_per_head=None if model.kv_cache._early is None else model.kv_cache._early["E"],
                                 value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1),
                                 scan_roofline={"us_per_launch": round(rf["us_per_launch"], 3), "algorithmic_bytes_per_launch": rf["algorithmic_bytes"],
@@ -963,6 +968,20 @@ def main(argv=None):
                            chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4, launch_mode=r["mode"],
                            state_build_s=round(tb, 1), v_table="pinned host memory",
                            fetch_launch=measure_fetch_launch(model, ctxb, args.walk_step, steps=2))
+                if not args.no_batched_resident:
+                    # the same batch with 512 resident chunk slots per head (NOT the reference's policy - its resident set is the last
+                    # selection, 256 slots): identical selections and outputs, fewer chunks over the link the batch sits on
+                    try:
+                        model = cache = None
+                        free_model()
+                        model, _, ctxr, _, tbr = build_model(args.workload, a2, rank, dev, resident_sets=512)
+                        rr = run_decode(model, a2, ctxr, 16, 4, args.walk_step, seed=99 + rank)
+                        ent["resident_512"] = dict(value=round(rr["value"], 2), ms_per_step=round(rr["ms_per_step"], 4),
+                                                   chunk_hit_rate=round(rr["hit_rate"], 4), steps=16, warmup=4, state_build_s=round(tbr, 1),
+                                                   note="--resident-sets 512: least-recently-selected replacement over 512 slots per head; "
+                                                        "not the reference's resident set, not the headline")
+                    except (MemoryError, RuntimeError) as e:
+                        ent["resident_512"] = dict(skipped=f"{type(e).__name__}: {str(e)[:200]}")
                 if b == 24:
                     ent["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100",
                                                              "source": "index.html:210-214 (config test/e2e.py:63-68)",

@@ -141,19 +141,21 @@ def sparse_attention(q, k, v, kv_len, scale):
     return out, out32
 
 
-def sparse_attention_p16(q, k, v, kv_len, scale, grp, ord_):
+def sparse_attention_p16(q, k, v, kv_len, scale, grp, ord_, with_flip=False):
     """sparse_attention with the softmax weights rounded to bf16 where the device kernels round them (flash-attn, the
     reference's attention, casts P to bf16 before P.V: models/base.py:341).  grp / ord_ int32 [bs, kv_heads, kv_len]: rounding
     group of every row (-1: never rounded) and its step inside the group (see oracle_sparse_attention_p16).
-    -> (out bf16, out f32)."""
+    -> (out bf16, out f32[, flip f32: the largest |weight x v| of a rounded row per output - one flipped bf16 rounding of a
+    weight moves the output by at most 2^-7 times it])."""
     bs, qh, d = q.shape
     kvh, rows = k.shape[1], k.shape[2]
     assert grp.dtype == torch.int32 and ord_.dtype == torch.int32 and grp.shape == (bs, kvh, kv_len) == ord_.shape
     out = torch.empty(bs, qh, d, dtype=torch.bfloat16)
     out32 = torch.empty(bs, qh, d, dtype=torch.float32)
+    flip = torch.empty(bs, qh, d, dtype=torch.float32) if with_flip else None
     lib().oracle_sparse_attention_p16(_p(q), _p(k), _p(v), _p(out), _p(out32), _i(bs), _i(qh), _i(kvh), _i(d),
-                                      _i(kv_len), _l(rows), _f(scale), _p(grp), _p(ord_))
-    return out, out32
+                                      _i(kv_len), _l(rows), _f(scale), _p(grp), _p(ord_), _p(flip))
+    return (out, out32, flip) if with_flip else (out, out32)
 
 
 def chunk_stats(k_ctx):

@@ -580,11 +580,14 @@ ORACLE_API void oracle_sparse_attention(const uint16_t *q, const uint16_t *k, co
  *                                                                       skv_attn_body.h `ps += p0 + p1`, skv_rebuild.hip `l += pk`)
  * with s_i = f32( q . k_i * scale ) and M the row maximum; sums in double, one final rounding.  What is left between
  * this and the device is f32 summation order, the 2-ulp error of the device's fast exp and the rare weight whose bf16
- * rounding flips because of them. */
+ * rounding flips because of them (the device's score differs from s_i in its last f32 bits: a weight that lies within
+ * ~1e-6 relative of a bf16 rounding boundary lands on the neighbouring bf16 value, one ulp = at most 2^-7 relative, away).
+ * flip_f32 (nullable, [bs][q_heads][D]): max over the ROUNDED rows of weight_i |v_i[d]| / normaliser - what ONE such flip
+ * can move an output by is at most 2^-7 times this. */
 ORACLE_API void oracle_sparse_attention_p16(const uint16_t *q, const uint16_t *k, const uint16_t *v, uint16_t *out,
                                             float *out_f32, int bs, int q_heads, int kv_heads, int head_dim,
                                             int kv_len, long kv_stride_rows, float scale, const int32_t *grp,
-                                            const int32_t *ord) {
+                                            const int32_t *ord, float *flip_f32) {
     int G = q_heads / kv_heads;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < bs; ++b)
@@ -630,11 +633,16 @@ ORACLE_API void oracle_sparse_attention_p16(const uint16_t *q, const uint16_t *k
                 }
             }
             for (int d = 0; d < head_dim; ++d) {
-                double acc = 0;
-                for (int j = 0; j < kv_len; ++j) acc += w[j] * (double)bf2f(vp[(size_t)j * head_dim + d]);
+                double acc = 0, big = 0;
+                for (int j = 0; j < kv_len; ++j) {
+                    double t = w[j] * (double)bf2f(vp[(size_t)j * head_dim + d]);
+                    acc += t;
+                    if (gp[j] >= 0 && fabs(t) > big) big = fabs(t);
+                }
                 float r = (float)(acc / den);
                 if (out) out[((size_t)b * q_heads + qh) * head_dim + d] = f2bf(r);
                 if (out_f32) out_f32[((size_t)b * q_heads + qh) * head_dim + d] = r;
+                if (flip_f32) flip_f32[((size_t)b * q_heads + qh) * head_dim + d] = (float)(big / den);
             }
             free(mref);
             free(w);

@@ -19,7 +19,11 @@ from util import rope_pair_bound
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928), "glm4_200k": ("GLM_4_9B_1M", 204800)}
+# name: (model config, context tokens, sparse budget, landmarks per head, default early-fetch chunks per head)
+SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928, 2048, 15560, 28), "glm4_200k": ("GLM_4_9B_1M", 204800, 2048, 25544, 64),
+          # the reference's 244K regime (test/e2e.py:50-55): budget 4096 -> S = 512, 96 outlier chunks, 122 scan tiles per head,
+          # 64 miss tiles + 24 splits = 88 attention records per head
+          "llama31_244k_b4096": ("LLAMA_3_1_8B", 249856, 4096, 31128, 28)}
 REPLAYS = 6
 _RUNS = {}
 
@@ -32,8 +36,8 @@ def _run(shape, early):
     if key in _RUNS:
         return _RUNS[key]
     from shadowkv_amd import llama
-    cfg_name, ctx = SHAPES[shape]
-    m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=2048, rank=160,
+    cfg_name, ctx, budget = SHAPES[shape][:3]
+    m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=budget, rank=160,
                         chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
     llama.build_synthetic_context(m, ctx, seed=11)
     if early:
@@ -48,12 +52,13 @@ def _run(shape, early):
         if early:
             pulled.append([int(m.kv_cache.early_fetch_counts(l).sum()) for l in range(m.num_layers)])
     torch.cuda.synchronize()
+    m.shape_name = shape
     _RUNS[key] = (m, tokens, pulled if early else None)
     return _RUNS[key]
 
 
-@pytest.fixture(scope="module", params=[("llama31_122k", False), ("llama31_122k", True), ("glm4_200k", True)],
-                ids=["llama31_122k-plain", "llama31_122k-early28", "glm4_200k-early64"])
+@pytest.fixture(scope="module", params=[("llama31_122k", False), ("llama31_122k", True), ("glm4_200k", True), ("llama31_244k_b4096", True)],
+                ids=["llama31_122k-plain", "llama31_122k-early28", "glm4_200k-early64", "llama31_244k_b4096-early"])
 def decoded(request):
     return _run(*request.param)[0]
 
@@ -63,7 +68,8 @@ def test_sparse_region_holds_the_chunks_its_ids_name(decoded):
     c = m.kv_cache
     glm = m.cfg.rope_style == "glm"
     C, D, S = c.chunk_size, c.head_dim, c.select_sets
-    assert (c.sparse_start, c.sparse_end, S) == (448, 2496, 256)
+    budget = SHAPES[m.shape_name][2]
+    assert (c.sparse_start, c.sparse_end, S) == {2048: (448, 2496, 256), 4096: (832, 4928, 512)}[budget]
     for l in range(m.num_layers):
         lm_ids = c.k_landmark_idx[l][0]                                   # [kv, N]
         for h in range(c.num_key_value_heads):
@@ -95,7 +101,7 @@ def test_generated_rows_and_counters(decoded):
     m = decoded
     c = m.kv_cache
     n = 2 + REPLAYS                                                        # 2 eager warm-up steps + the replays
-    ctx = SHAPES["glm4_200k" if m.cfg.rope_style == "glm" else "llama31_122k"][1]
+    ctx = SHAPES[m.shape_name][1]
     assert c.kv_offset == ctx + n and c.gen_offset == n
     for l in range(m.num_layers):
         for buf in (c.k_cache_buffer, c.v_cache_buffer):
@@ -123,7 +129,7 @@ def test_rebuild_is_homogeneous_at_full_size(decoded):
     assert torch.equal(out[1], 2.0 * out[0])
 
 
-@pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k"])
+@pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k", "llama31_244k_b4096"])
 def test_early_fetch_changes_no_bit_at_full_size(shape):
     """The headline's default path against the same captured steps without the early fetch, at the size the headline runs
     it (61 / 100 flag tiles per head, early_of over 15,616 / 25,600 chunks): sampled tokens, slot -> chunk map, hit counts
@@ -133,8 +139,7 @@ def test_early_fetch_changes_no_bit_at_full_size(shape):
     mp, tok_p, _ = _run(shape, False)
     ce, cp = me.kv_cache, mp.kv_cache
     E = ce._early["E"]
-    assert E == (64 if shape == "glm4_200k" else 28)
-    assert ce.k_landmark.shape[-2] == (25544 if shape == "glm4_200k" else 15560)
+    assert E == SHAPES[shape][4] and ce.k_landmark.shape[-2] == SHAPES[shape][3]
     assert tok_e == tok_p, (tok_e, tok_p)
     assert torch.equal(ce.position_ids, cp.position_ids)
     assert torch.equal(ce._cnts_layers, cp._cnts_layers)

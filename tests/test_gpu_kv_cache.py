@@ -299,14 +299,15 @@ def test_overlapped_attention_equals_fetch_then_attend(case):
                             o.cpu().float().view(1, Hq, D), qd.cpu().view(1, Hq, D), kc, vc, rows, 1.0 / math.sqrt(D), labels)
 
 
-def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None, max_length=None):
+def _headline_cache(kv_heads, glm, L=8192, seed=11, resident_sets=None, max_length=None, budget=2048):
     """ShadowKVCache_CPU with the headline layout (budget 2,048 -> S = 256, 48 outlier chunks, sparse region rows
-    [448, 2496), 96 generated rows) over an L-token synthetic context whose keys are exactly rank 160."""
+    [448, 2496), 96 generated rows) over an L-token synthetic context whose keys are exactly rank 160.  budget 1,024 / 4,096:
+    the reference's 60K / 244K regimes (test/e2e.py:35-116): S = 128 / 512, 24 / 96 outlier chunks."""
     from shadowkv_amd import llama
     from shadowkv_amd.kv_cache import ShadowKVCache_CPU
     mc = llama.ModelConfig(num_hidden_layers=1, num_key_value_heads=kv_heads, rope_style="glm" if glm else "neox",
                            rope_theta=10000.0 if glm else 500000.0)
-    cache = ShadowKVCache_CPU(mc, batch_size=1, max_length=max_length or L, device=DEV, dtype=torch.bfloat16, sparse_budget=2048,
+    cache = ShadowKVCache_CPU(mc, batch_size=1, max_length=max_length or L, device=DEV, dtype=torch.bfloat16, sparse_budget=budget,
                               chunk_size=8, rank=160, resident_sets=resident_sets)
     cs, g = _headline_prefill(cache, L, seed)
     return cache, cs, g
@@ -339,21 +340,29 @@ def _headline_prefill(cache, L, seed):
     return cs, g
 
 
-@pytest.mark.parametrize("kv_heads,glm,hit,ctx", [(8, False, 0.67, 8192), (8, False, 0.0, 8192), (8, False, 1.0, 8192),
-                                                  (4, False, 0.67, 8192), (4, True, 0.0, 8192), (4, True, 0.67, 8192),
-                                                  # BASELINE.json configs 2 and 3 at their full per-layer size
-                                                  (8, False, 0.67, 131072), (4, True, 0.67, 204800)])
-def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm, hit, ctx):
+@pytest.mark.parametrize("kv_heads,glm,hit,ctx,budget", [
+    (8, False, 0.67, 8192, 2048), (8, False, 0.0, 8192, 2048), (8, False, 1.0, 8192, 2048),
+    (4, False, 0.67, 8192, 2048), (4, True, 0.0, 8192, 2048), (4, True, 0.67, 8192, 2048),
+    # BASELINE.json configs 2 and 3 at their full per-layer size
+    (8, False, 0.67, 131072, 2048), (4, True, 0.67, 204800, 2048),
+    # the reference's other two regimes (test/e2e.py:35-116): budget 4096 (S = 512: 64 miss tiles + 24 splits = 88 attention
+    # records per head) incl. one layer at the full 244K size, G = 4 and G = 8 (Yi-9B / GLM-4); budget 1024 (S = 128) at 60K
+    (8, False, 0.6, 32768, 4096), (8, False, 0.0, 32768, 4096), (4, False, 0.6, 32768, 4096), (4, True, 0.6, 32768, 4096),
+    (8, False, 0.6, 249856, 4096), (8, False, 0.6, 61440, 1024), (4, True, 0.0, 16384, 1024)])
+def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm, hit, ctx, budget):
     """The path the headline number runs on (bench.py defaults: in-place layout, attention over the resident rows inside
     the fetch launch, miss tiles attended where they are built, merge kernel) at the headline shape: S = 256 chunks, sparse region [448, 2496),
     kv_len = 2,499, G = 4 and G = 8, chunk hit rates 0 / 0.67 / 1; also one layer of the 131,072-token Llama-3-1048K and of
     the 204,800-token GLM-4 configuration (BASELINE.json configs 2 and 3) at full size.  Checked against the oracle: selected set bit-exact,
     V rows byte-exact against the host table, K rows within the one-ulp-flip bound of the oracle's rebuild, and the
     attention output against the oracle's F32 result over the device's K / V bytes at 1e-3 |ref| + half a bf16 ulp."""
-    cache, cs, g = _headline_cache(kv_heads, glm, L=ctx)
+    cache, cs, g = _headline_cache(kv_heads, glm, L=ctx, budget=budget)
     Hq, D, C, S = 32, 128, 8, cache.select_sets
     Gq = Hq // kv_heads
-    assert S == 256 and cache.sparse_start == 448 and cache.sparse_end == 2496 and cache.k_cache_buffer.shape[-2] == 2592
+    n_out = budget // 1024 * 24                                              # outlier chunks (kv_cache.py:548)
+    assert S == budget // 8 and cache.sparse_start == 64 + 8 * n_out and cache.sparse_end == cache.sparse_start + budget
+    assert cache.k_cache_buffer.shape[-2] == cache.sparse_end + 96 and cache.can_overlap_attention()
+    assert (S, cache.sparse_start, cache.sparse_end) == {2048: (256, 448, 2496), 4096: (512, 832, 4928), 1024: (128, 256, 1280)}[budget]
     q = (torch.randn(1, Hq, 1, D, device=DEV, generator=g) * 1.5).bfloat16()
     gen = 3
     for buf in (cache.k_cache_buffer, cache.v_cache_buffer):
@@ -398,7 +407,7 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     (oracle.apply_rotary_pos_emb_push_cache_opt_glm if glm else oracle.apply_rotary_pos_emb_push_cache_opt)(
         pre, csc, ids32, kor, zero, *ints)
     kd = (kor.float() - kbuf.float()).abs()[0][:, cache.sparse_start:cache.sparse_end]
-    record_parity(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}]",
+    record_parity(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}-b{budget}]",
                   ulp_diff_bf16(kor[0][:, cache.sparse_start:cache.sparse_end], kbuf[0][:, cache.sparse_start:cache.sparse_end]),
                   "post-RoPE")     # (hit rows were placed by the prefill's torch einsum, miss rows by the rebuild kernel)
     bound = rope_pair_bound(pre[0], glm)
@@ -407,7 +416,7 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     # (the miss tiles' P.V runs on the MFMA with bf16 weights, like flash-attn's: the oracle rounds the same weights against
     # the same tile maxima, from the slots the selection assigned)
     qc = q.cpu().view(1, Hq, D).contiguous()
-    a32 = check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}]",
+    a32 = check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}-b{budget}]",
                           out.view(1, Hq, D).cpu().float(), qc, kbuf, vbuf, kv_len, 1 / math.sqrt(D), overlapped_pass_labels(cache, kv_len))
     _, aabs = oracle.sparse_attention(qc, kbuf, vbuf.abs(), kv_len, 1 / math.sqrt(D))
     tol = attention_tolerance(a32, aabs)
@@ -417,11 +426,11 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
     out2 = cache.select_fetch_attend_inplace(0, q, cs, kv_len=0, kv_len_dev=kvd)
     torch.cuda.synchronize()
     assert cache.cnts.cpu().tolist() == [S] * kv_heads
-    check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}] all hits",
+    check_attention(f"test_overlapped_attention_at_headline_shape[kv{kv_heads}-glm{int(glm)}-hit{hit}-ctx{ctx}-b{budget}] all hits",
                     out2.view(1, Hq, D).cpu().float(), qc, kbuf, vbuf, kv_len, 1 / math.sqrt(D), overlapped_pass_labels(cache, kv_len))
     assert int((overlapped_pass_labels(cache, kv_len)[0] >= 0).sum()) == 0      # (no miss tile: every weight stays f32)
     with pytest.raises(ValueError):
-        cache.select_fetch_attend_inplace(0, q, cs, kv_len=2593)
+        cache.select_fetch_attend_inplace(0, q, cs, kv_len=cache.k_cache_buffer.shape[-2] + 1)
 
 
 @pytest.mark.parametrize("kv_heads,glm,overlap", [(8, False, True), (8, False, False), (4, True, True)])
@@ -506,14 +515,15 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
         big.get_retrieval_position_ids(0, q)
 
 
-@pytest.mark.parametrize("kv_heads,glm", [(8, False), (4, True)])
-def test_early_fetch_changes_no_bit(kv_heads, glm):
+@pytest.mark.parametrize("kv_heads,glm,budget", [(8, False, 2048), (4, True, 2048), (8, False, 4096), (4, True, 4096), (8, False, 1024)])
+def test_early_fetch_changes_no_bit(kv_heads, glm, budget):
     """Speculative early V fetch (csrc/skv_early.hip): flagged in the scan launch, pulled by a launch on a side stream beside
     normalise + top-k, consumed from HBM staging by the fetch launch.  Against the same steps without it: attention output,
     selection bookkeeping and both caches bit for bit; the V rows of the selected chunks equal the host table; and the
     prediction does fire (chunks are pulled early once a previous step has left its thresholds)."""
-    ca, cs, g = _headline_cache(kv_heads, glm, L=16384, seed=23)
-    cb, _, _ = _headline_cache(kv_heads, glm, L=16384, seed=23)
+    L = 16384 if budget <= 2048 else 32768
+    ca, cs, g = _headline_cache(kv_heads, glm, L=L, seed=23, budget=budget)
+    cb, _, _ = _headline_cache(kv_heads, glm, L=L, seed=23, budget=budget)
     ca.enable_early_fetch()
     kv_len = ca.sparse_end + 2
     q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()

@@ -97,19 +97,35 @@ def check_attention(test, got32, q, k, v, kv_len, scale, labels):
     import oracle
     _, a32 = oracle.sparse_attention(q, k, v, kv_len, scale)
     _, aabs = oracle.sparse_attention(q, k, v.abs(), kv_len, scale)
-    ref = a32 if labels is None else oracle.sparse_attention_p16(q, k, v, kv_len, scale, *labels)[1]
+    flip = None
+    if labels is None:
+        ref = a32
+    else:
+        _, ref, flip = oracle.sparse_attention_p16(q, k, v, kv_len, scale, *labels, with_flip=True)
     err, tol = (got32 - ref).abs(), attention_tolerance(ref)
     err32 = (got32 - a32).abs()
     b32 = attention_tolerance(a32)
+    over = err > tol
+    heads_over = int(over.flatten(0, -2).any(dim=-1).sum())
+    n_heads = err.numel() // err.shape[-1]
     try:
         with open_parity_record("attention_parity.txt") as f:
             f.write(f"{test:64s} values {err.numel():7d} | vs the {'bf16-P' if labels is not None else 'f32-P '} oracle: max |err| {float(err.max()):.3e}"
-                    f"  max err / bound {float((err / tol).max()):6.3f}  over the bound {int((err > tol).sum()):4d} | vs the f32-P oracle:"
-                    f" max err / bound {float((err32 / b32).max()):6.3f}  over the bound {int((err32 > b32).sum()):4d}\n")
+                    f"  max err / bound {float((err / tol).max()):6.3f}  over the bound {int(over.sum()):4d} (in {heads_over} of {n_heads} heads)"
+                    f" | vs the f32-P oracle: max err / bound {float((err32 / b32).max()):6.3f}  over the bound {int((err32 > b32).sum()):4d}\n")
     except OSError:
         pass
-    assert bool((err <= tol).all()), f"{test}: attention exceeds 1e-3 |ref| + half an ulp + 1e-5 by {float((err - tol).max()):.3e} " \
-                                     f"({int((err > tol).sum())} values)"
+    if flip is None:
+        assert not bool(over.any()), f"{test}: attention exceeds 1e-3 |ref| + half an ulp + 1e-5 by {float((err - tol).max()):.3e} " \
+                                     f"({int(over.sum())} values)"
+    else:
+        # A weight within ~1e-6 relative of a bf16 rounding boundary can land on the other side on the device (its f32 score and
+        # fast exp differ from the oracle's in the last bits): ONE flipped weight moves the outputs of its head by at most one
+        # bf16 ulp (2^-7 relative) of that weight's contribution.  Such heads are rare (measured: 2 of ~90 checks on MI355X had
+        # one) - at most 5 % of the heads (at least one) may hold values over the tight bound, each within the one-flip bound.
+        assert bool((err <= tol + 2.0 ** -7 * flip).all()), \
+            f"{test}: attention exceeds 1e-3 |ref| + half an ulp + 1e-5 + one flipped bf16 weight by {float((err - tol - 2.0 ** -7 * flip).max()):.3e}"
+        assert heads_over <= max(1, n_heads // 20), f"{test}: {heads_over} of {n_heads} heads exceed the tight bound ({int(over.sum())} values)"
     assert bool((err32 <= attention_tolerance(a32, aabs)).all()), f"{test}: attention exceeds the bf16-weight error model"
     return a32
 
