@@ -9,7 +9,7 @@
 
 // launchers (defined in the kernel files)
 int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
-                     float alpha, hipStream_t st, const EarlyHooks* hooks = nullptr);
+                     float alpha, hipStream_t st, const EarlyHooks* hooks = nullptr, const FusedSel* fused = nullptr);
 int skv_launch_softmax_final_apply(const void* D, float* pmax, float* psum, void* P, int B, int m, int N,
                                    hipStream_t st);
 int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float* psum, void* P, void* score,

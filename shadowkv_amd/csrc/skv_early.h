@@ -55,8 +55,12 @@ static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
 // scan.  Candidate i = (tile i / K, entry i % K) is real when its entry index is below the tile's count; a thread's
 // candidates are i = c * THREADS + tid, and every load is issued unconditionally (a load under `if` would be followed by
 // a wait for its round trip - 16 of them in a row).
+// publish = false (fused selection: several workgroups of a head build the SAME list, each for itself - only one of them may
+// maintain early_of / early_ids / early_cnt): nothing is written to global memory.  s_list (nullable): the kept ids [E] and,
+// in s_list[EF_MAX_E], their number - for a role that goes on in the same workgroup (skv_early_prep_pull_role).
 template <int THREADS>
-__device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem) {
+__device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem, bool publish = true,
+                                                    int* s_list = nullptr) {
     constexpr int CPT = EF_MAX_CAND / THREADS;
     const int n_chunks = eh.n_chunks, E = eh.E, T = eh.T, N = eh.N, R = eh.R;
     const int words = (n_chunks + 31) / 32;
@@ -83,7 +87,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
 #pragma unroll
     for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
-    if (tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
+    if (publish && tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -111,14 +115,20 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clears above are in L2)
     const int kincl = ef_block_scan_incl<THREADS>(nkeep, s_w, tid);
-    if (tid == THREADS - 1) eh.early_cnt[b] = min(kincl, E);
+    if (tid == THREADS - 1) {
+        if (publish) eh.early_cnt[b] = min(kincl, E);
+        if (s_list) s_list[EF_MAX_E] = min(kincl, E);
+    }
     int pos = kincl - nkeep;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         if ((keepm >> c) & 1u) {
             if (pos < E) {
-                eh.early_ids[(size_t)b * E + pos] = (int)id[c];
-                eh.early_of[(size_t)b * n_chunks + id[c]] = (short)pos;
+                if (publish) {
+                    eh.early_ids[(size_t)b * E + pos] = (int)id[c];
+                    eh.early_of[(size_t)b * n_chunks + id[c]] = (short)pos;
+                }
+                if (s_list) s_list[pos] = (int)id[c];
             }
             ++pos;
         }
@@ -130,12 +140,13 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
 // head - 4 CUs at GLM-4's shape - pulled 393 KB in 15 us = 26 GB/s and stretched the top-k launch from 12.7 to 18.5 us; with
 // four per head it ends with the top-k, 12.6 us.)  s_sel: EF_MAX_E ints.
 #define SKV_EARLY_PULL_WGS 4
+// list_in_lds: s_sel[0 .. E) and s_sel[EF_MAX_E] were filled by skv_early_prep_role in this workgroup (fused selection)
 template <int THREADS>
-__device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* s_sel) {
+__device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* s_sel, bool list_in_lds = false) {
     const int E = eh.E;
-    const int n_sel = min(eh.early_cnt[b], E);
-    if (tid < EF_MAX_E) s_sel[tid] = tid < E ? eh.early_ids[(size_t)b * E + tid] : 0;
+    if (!list_in_lds && tid < EF_MAX_E) s_sel[tid] = tid < E ? eh.early_ids[(size_t)b * E + tid] : 0;
     __syncthreads();
+    const int n_sel = list_in_lds ? min(s_sel[EF_MAX_E], E) : min(eh.early_cnt[b], E);
     // chunk e = 128 units of 16 B; 8 requests per thread in flight (unconditional loads through a selected pointer: a load
     // under `if` would be followed by a wait for the PCIe round trip)
     const u32x4* const hb = reinterpret_cast<const u32x4*>(eh.v_host) + (long long)b * eh.v_host_stride_u128;
@@ -157,4 +168,20 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
         for (int k = 0; k < 8; ++k)
             if (dst[k] >= 0) sb[dst[k]] = v[k];
     }
+}
+
+// Fused selection: there is no normalise launch for the list role to ride in, so every pull workgroup of a head builds the
+// head's list itself (same inputs -> same list; ~3 us: two dependent round trips and a block scan) and pulls its share;
+// workgroup `part` == 0 also publishes the list for the fetch launch (early_ids, early_of, early_cnt).  The list's "resident"
+// input is the slot -> chunk map the selection workgroup of the same launch rewrites at ITS end (~10 us later): a late pull
+// workgroup that saw some of the new ids would only skip / pull a few other chunks - prediction, never a result.
+// smem: [words(n_chunks) + 64] ints of the list role, then EF_MAX_E + 1 ints of the list.
+template <int THREADS>
+__device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* smem) {
+    int* const s_list = smem + (eh.n_chunks + 31) / 32 + 64;
+    if (tid <= EF_MAX_E) s_list[tid] = 0;
+    __syncthreads();
+    skv_early_prep_role<THREADS>(eh, b, tid, smem, part == 0, s_list);
+    __syncthreads();
+    skv_early_pull_role<THREADS>(eh, b, part, tid, s_list, true);
 }

@@ -28,6 +28,17 @@ struct EarlyConsume {
     int early_chunks, early_max;
 };
 
+// Fused selection (round 4; skv_select.hip "logit-domain prefilter"): the scan launch leaves, per landmark slot, a 15-bit
+// order-preserving KEY of kappa_j = max_g (logit_gj - ctil_g) - the group maximum in the logit domain under the PREVIOUS step's
+// log-normalisers ctil_g - and the slot's G logits contiguously (Dt [B][N][G]) instead of D [B][G][N]; the top-k launch then
+// finds the exact top-S without a normalise launch (see skv_topk3_kernel).  ctil null = the three-launch path.
+struct FusedSel {
+    const float* ctil;        // [B][G] in: log-normalisers (m_g + ln s_g) the keys are taken against (any finite values are valid)
+    uint16_t* keys;           // [B][key_stride] out
+    void* Dt;                 // [B][N][G] bf16 out
+    int key_stride;
+};
+
 // Hooks of the speculative early V fetch in the selection launches (skv_select.hip, roles in skv_early.h); dthr_in null = off.
 //   scan:      a landmark slot whose logit reaches dthr_in[b][g] for some query head g is FLAGGED (it would have made the
 //              previous step's top-k): per tile the first SKV_EARLY_K flagged slots go to flag_slot, their number to flag_cnt.

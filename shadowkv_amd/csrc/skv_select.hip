@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
     bf16_t* __restrict__ D,          // [B][G][N]
     float* __restrict__ part_max,    // [B][T][G]
     float* __restrict__ part_sum,    // [B][T][G]
-    int N, int T, float alpha, EarlyHooks eh) {
+    int N, int T, float alpha, EarlyHooks eh, FusedSel fs) {
     constexpr int ITERS = 64 / WAVES;               // 4-row wave-instructions per wave
     constexpr int GH = G > 8 ? 4 : G;               // query heads per pass
     constexpr int PASSES = G / GH;
@@ -190,6 +190,36 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         return;
     }
 
+    // fused selection (fs.ctil != nullptr): per slot the 15-bit key of kappa = max_g (logit_g - ctil_g) and the slot's G logits
+    // side by side (Dt [B][N][G]) - every wave takes 256 / WAVES columns, one lane per column (G LDS reads of 2 B, a few VALU
+    // operations, one 2-B and one 2G-B store per lane: 64-B / 16G-B runs per wave); D [B][G][N] is not written then
+    const bool fused = ABL == 0 && fs.ctil != nullptr;
+    if (fused) {
+        constexpr int CPW = SKV_TILE / WAVES;                // columns per wave: 16 (G <= 4) or 32 (G = 8)
+        const int col = wave * CPW + lane, j = t * SKV_TILE + col;
+        if (lane < CPW && j < N) {
+            float kap = -INFINITY;
+            uint32_t pk[(G + 1) / 2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bf16_t d = sD[g][col];
+                kap = fmaxf(kap, bf2f(d) - fs.ctil[(size_t)b * G + g]);
+                if (g & 1) pk[g / 2] |= (uint32_t)d << 16;
+                else pk[g / 2] = d;
+            }
+            // (clamped below zero: K_j = D - c <= 0 always, a kappa above it is a stale ctil - the clamp is monotone, so the
+            // candidate rule stands, and it keeps every key of a row within a few hundred codes: one histogram window)
+            fs.keys[(size_t)b * fs.key_stride + j] = skv_kappa_key(fminf(kap, -0x1p-12f));
+            bf16_t* dt = reinterpret_cast<bf16_t*>(fs.Dt) + ((size_t)b * N + j) * G;
+            if constexpr (G == 8) *reinterpret_cast<u32x4*>(dt) = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+            else if constexpr (G == 4) *reinterpret_cast<u32x2*>(dt) = (u32x2){pk[0], pk[1]};
+            else if constexpr (G == 2) *reinterpret_cast<uint32_t*>(dt) = pk[0];
+            else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) dt[g] = sD[g][col];
+            }
+        }
+    }
     // early-fetch flags (off: eh.dthr_in == nullptr): one wave that has no query head in the statistics below (or wave 0)
     // compares its 4 columns' logits with the heads' thresholds and compacts the flagged slots of the tile
     if (flag_wave) {
@@ -239,7 +269,9 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
             if (t * SKV_TILE + c0 + k < N) e += exp_to_fixed(spec_exp(dv[k] - m));
         e = wave_sum_u64_dpp(e);
         bf16_t* drow = D + ((size_t)b * G + g) * N + (size_t)t * SKV_TILE + c0;
-        if (t * SKV_TILE + c0 + 3 < N && (((size_t)drow) & 7) == 0) {
+        if (fused) {
+            // (the logits went out slot-major above)
+        } else if (t * SKV_TILE + c0 + 3 < N && (((size_t)drow) & 7) == 0) {
             *reinterpret_cast<u32x2*>(drow) = *reinterpret_cast<const u32x2*>(&sD[g][c0]);
         } else {
 #pragma unroll
@@ -736,6 +768,231 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused selection front end (round 4): exact top-S WITHOUT the normalise launch.
+//
+// The three-launch path needs score_j = max_g bf16(e(D_gj - m_g) inv_g) for every slot, i.e. the finals (m_g, 1 / s_g) of the
+// softmax rows BEFORE any score exists - a grid-wide dependency that costs a launch (6.1 us of a 57 us chain, during which the
+// PCIe link, the roof of the path, sits idle).  But which slots can be in the top S is decided by far fewer of them:
+//   * K_j = max_g (D_gj - c_g), c_g = m_g + ln s_g, is score_j in the logit domain: score_j ~ exp(K_j) up to the bf16
+//     rounding of P and the f32 rounding of e() and 1 / s (relative 2^-9 + ~1e-6);
+//   * the scan launch cannot know c_g, but it knows the PREVIOUS step's: it emits kappa_j = max_g (D_gj - ctil_g) as a 15-bit
+//     monotone key (skv_kappa_key).  With delta_g = c_g - ctil_g:  kappa_j - max delta <= K_j <= kappa_j - min delta;
+//   * let k15 = the S-th largest key: at least S slots a have kappa_a >= low(k15) (skv_kappa_key_low).  A slot j with
+//       kappa_j < theta := low(k15) - (max delta - min delta) - SLACK
+//     has K_j <= kappa_j - min delta < low(k15) - max delta - SLACK <= K_a - SLACK for those S slots a, hence
+//       score_j <= bf16(exp(K_j)(1 + 2e-6)) <= exp(K_a) e^-SLACK (1 + 2^-9 + 2e-6) < exp(K_a)(1 - 2^-9 - 2e-6) <= score_a
+//     for SLACK = 2^-4 (e^-0.0625 = 0.939) whenever score_a is a normal bf16 number: j is STRICTLY below S slots - it is
+//     neither in the top S nor tied with its last member, whatever the tie rule.  key(kappa_j) < key(theta) implies
+//     kappa_j < theta (monotone key), so the candidates are the slots whose key reaches key(theta);
+//   * the candidates (S plus a few dozen when the c_g move together, as they do from step to step; all that matters is the
+//     SPREAD of the delta_g, a common shift cancels) are evaluated EXACTLY - the finals by the contract's reduction
+//     (softmax_finalize), P = bf16(spec_exp(D - m_g) inv_g), max over g: the normalise kernel's arithmetic - and the exact
+//     top S with ties to the lowest slot is taken among them (second threshold search, ordered placement).
+// More than T3_CAND candidates (first step: ctil = 0; a jump of the query), or an S-th score that is not a normal bf16
+// number: every thread evaluates ALL its slots exactly and the standard front end runs on those keys - same result, the
+// three-launch path's arithmetic, ~5 us slower on that step.  Nothing is approximate: oracle/shadowkv_oracle.c
+// (oracle_fused_candidates) restates the candidate rule and the tests check top-S subset-of candidates on every input.
+// Returns true when s_cur / s_id hold the selection; false: w[] holds the exact score keys (padding 0), histogram zeroed.
+// ---------------------------------------------------------------------------------------
+struct FusedTop {
+    const void* Dt;           // [B][N][G] bf16 (scan launch, FusedSel); null = scores in (three-launch path)
+    const float* part_max;    // [B][T][G]
+    const float* part_sum;
+    float* ctil;              // [B][G] in: what the scan's keys were taken against; out: this step's c_g
+    int T;
+};
+
+template <int FG>
+__device__ __forceinline__ uint32_t t3_exact_key(const bf16_t* __restrict__ drow, const float* s_fin) {
+    bf16_t d[FG];
+    if constexpr (FG == 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(drow);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { d[2 * x] = (bf16_t)(v[x] & 0xffffu); d[2 * x + 1] = (bf16_t)(v[x] >> 16); }
+    } else if constexpr (FG == 4) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(drow);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { d[2 * x] = (bf16_t)(v[x] & 0xffffu); d[2 * x + 1] = (bf16_t)(v[x] >> 16); }
+    } else {
+#pragma unroll
+        for (int g = 0; g < FG; ++g) d[g] = drow[g];
+    }
+    bf16_t best = 0;
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {       // the normalise kernel's arithmetic (skv_normalize_groupmax_kernel), bit for bit
+        const bf16_t p = f2bf(spec_exp(bf2f(d[g]) - s_fin[2 * g]) * s_fin[2 * g + 1]);
+        best = p > best ? p : best;      // p >= 0: unsigned order == float order
+    }
+    return best;
+}
+
+template <int FG, int NW, typename F>
+__device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop& ft, const int64_t* __restrict__ lm_idx, const int b,
+                                               const int N, const int S, const int j0, const int tid, int* s_hist, int* s_w,
+                                               int* s_out, int* s_cur, long long* s_id, int* s_cand, float* s_fin,
+                                               const EarlyHooks& eh, F insert_resident) {
+    constexpr int NG = (NW + 15) / 16;
+    const int lane = tid & 63, wave = tid >> 6, T = ft.T;
+    const bf16_t* const Dt = reinterpret_cast<const bf16_t*>(ft.Dt) + (size_t)b * N * FG;
+    // (1) the tile partials of softmax row g = wave are REQUESTED now (<= 4 per lane: T <= 256) and reduced behind the key
+    //     search, in the contract's order: maximum; sum over tiles lane, lane + 64, .. in that order; the 16-lane tree; rows
+    float pmv[4], psv[4];
+    float my_ctil = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tt = lane + 64 * i;
+        const bool in = wave < FG && tt < T;
+        pmv[i] = in ? ft.part_max[((size_t)b * T + tt) * FG + wave] : -INFINITY;
+        psv[i] = in ? ft.part_sum[((size_t)b * T + tt) * FG + wave] : 0.0f;
+    }
+    if (wave < FG) my_ctil = ft.ctil[(size_t)b * FG + wave];
+    // (2) the S-th largest key
+    int thr15, ne15;
+    t2_find_threshold<NW>(w, T2_THREADS * (NW / 4) * 8 - N, S, tid, s_hist, s_w, s_out, thr15, ne15, insert_resident);
+    if (wave < FG) {
+        float m = fmaxf(fmaxf(pmv[0], pmv[1]), fmaxf(pmv[2], pmv[3]));
+        m = wave_max_dpp(m);
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < T) acc = acc + psv[i] * spec_exp(pmv[i] - m);
+        acc = row16_tree_sum(acc);
+        const int x = __float_as_int(acc);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+        if (lane == 0) {
+            const float inv = 1.0f / ((r0 + r1) + (r2 + r3));
+            const float c = m - __logf(inv);                     // c_g = m_g + ln s_g (prediction + margin only)
+            s_fin[2 * wave] = m;
+            s_fin[2 * wave + 1] = inv;
+            s_fin[2 * FG + wave] = c - my_ctil;                  // delta_g
+            ft.ctil[(size_t)b * FG + wave] = c;                  // the next step's scan takes its keys against this
+        }
+    }
+    {   // the histogram is searched again below (either path); all its readers are behind find_threshold's last barrier
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+        for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    __syncthreads();                                             // finals and deltas visible
+    // (3) candidate keys
+    int thr_lo;
+    {
+        float dmax = -INFINITY, dmin = INFINITY;
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+            dmax = fmaxf(dmax, s_fin[2 * FG + g]);
+            dmin = fminf(dmin, s_fin[2 * FG + g]);
+        }
+        const float theta = skv_kappa_key_low(thr15) - (dmax - dmin) - 0.0625f;
+        thr_lo = (theta == theta) ? (int)skv_kappa_key(theta) : 0;            // (NaN: every slot is a candidate)
+        thr_lo = min(thr_lo, thr15);
+    }
+    uint32_t mc[NG];
+    {
+        const uint32_t kge = (0x8000u - (uint32_t)thr_lo) * 0x10001u;       // keys are < 0x8000 (15 bits)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) mc[g] = 0u;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t te = w[i] + kge;
+            mc[i / 16] |= (((te >> 15) & 1u) | ((te >> 31) << 1)) << (2 * (i % 16));
+        }
+        if (j0 + NW * 2 > N) {                                   // padding (key 0) is never a candidate, whatever thr_lo
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int j = j0 + 2 * i;
+                if (j >= N) mc[i / 16] &= ~(1u << (2 * (i % 16)));
+                if (j + 1 >= N) mc[i / 16] &= ~(2u << (2 * (i % 16)));
+            }
+        }
+    }
+    int cc = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cc += __builtin_popcount(mc[g]);
+    const int cincl = block_scan_incl1(cc, s_w + 32, tid);
+    if (tid == T2_THREADS - 1) s_out[8] = cincl;
+    if (cincl <= T3_CAND) {                                      // (a thread beyond the limit implies C beyond it)
+        int o = cincl - cc;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            uint32_t m = mc[g];
+            while (m) {
+                s_cand[o++] = j0 + g * 32 + __builtin_ctz(m);
+                m &= m - 1;
+            }
+        }
+    }
+    __syncthreads();
+    const int C = s_out[8];
+    if (C <= T3_CAND) {
+        // (4) exact scores of the candidates, two per thread in slot order; their chunk ids travel with them
+        const int c0 = 2 * tid, c1 = 2 * tid + 1;
+        const int ja = c0 < C ? s_cand[c0] : -1, jb = c1 < C ? s_cand[c1] : -1;
+        long long ida = -1, idb = -1;
+        if (lm_idx != nullptr) {
+            ida = lm_idx[(size_t)b * N + max(ja, 0)];
+            idb = lm_idx[(size_t)b * N + max(jb, 0)];
+        } else {
+            ida = ja;
+            idb = jb;
+        }
+        const uint32_t ka = t3_exact_key<FG>(Dt + (size_t)max(ja, 0) * FG, s_fin);
+        const uint32_t kb = t3_exact_key<FG>(Dt + (size_t)max(jb, 0) * FG, s_fin);
+        const uint32_t w2[1] = {(ja >= 0 ? ka : 0u) | ((jb >= 0 ? kb : 0u) << 16)};
+        int thr, need_eq;
+        t2_find_threshold<1>(w2, 2 * T2_THREADS - C, S, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+        if (thr >= 0x0100) {                                     // a normal bf16 number: the strictness argument holds
+            if (eh.dthr_out != nullptr && tid < FG) {            // next step's flag thresholds (early fetch; prediction only)
+                const float kth = __uint_as_float((uint32_t)thr << 16);
+                const float mx = s_fin[2 * tid], inv = s_fin[2 * tid + 1];
+                eh.dthr_out[(size_t)b * FG + tid] = (kth > 0.f && inv > 0.f) ? mx + __logf(kth / inv) + eh.margin : INFINITY;
+            }
+            const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
+            const bool va = ja >= 0, vb = jb >= 0;
+            const int ga = va && lo > thr, gb = vb && hi > thr, ea = va && lo == thr, eb = vb && hi == thr;
+            const int packed = (ga + gb) | ((ea + eb) << 12);    // (<= 1,024 greater, <= 2,048 equal in all)
+            const int pincl = block_scan_incl1(packed, s_w + 48, tid);
+            const int pexcl = pincl - packed;
+            int gt_run = pexcl & 0xfff, eq_run = pexcl >> 12;
+            if (ga) {
+                const int pos = gt_run + min(eq_run, need_eq);
+                s_cur[pos] = ja;
+                s_id[pos] = ida;
+                ++gt_run;
+            } else if (ea) {
+                if (eq_run < need_eq) {
+                    s_cur[gt_run + eq_run] = ja;
+                    s_id[gt_run + eq_run] = ida;
+                }
+                ++eq_run;
+            }
+            if (gb) {
+                const int pos = gt_run + min(eq_run, need_eq);
+                s_cur[pos] = jb;
+                s_id[pos] = idb;
+            } else if (eb && eq_run < need_eq) {
+                s_cur[gt_run + eq_run] = jb;
+                s_id[gt_run + eq_run] = idb;
+            }
+            return true;
+        }
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);            // (never for softmax scores of a real head)
+#pragma unroll
+        for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    // (5) slow path: the exact score of EVERY slot of the thread; the caller runs the standard front end on these keys
+#pragma unroll 1
+    for (int i = 0; i < NW; ++i) {
+        const int j = j0 + 2 * i;
+        const uint32_t k0 = j < N ? t3_exact_key<FG>(Dt + (size_t)j * FG, s_fin) : 0u;
+        const uint32_t k1 = j + 1 < N ? t3_exact_key<FG>(Dt + (size_t)(j + 1) * FG, s_fin) : 0u;
+        w[i] = k0 | (k1 << 16);
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
 // K2b, second generation (default for N <= 131,072 scores per head): same results as the kernel above with a
 // shorter dependency chain and far fewer instructions per score.  One 1,024-thread workgroup per head runs on ONE
 // CU: every instruction a thread executes is issued 16 times on 4 SIMDs (about 20 cycles), so the kernel is bound by
@@ -757,7 +1014,7 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 // Padding (scores past N in the last thread's vectors) is rewritten to key 0 at load and its count is subtracted
 // from the bin of key 0; padding has the highest indices, so the tie rule never reaches it.
 // ---------------------------------------------------------------------------------------
-template <int SEGV>
+template <int SEGV, int FG = 0 /* query heads per KV head of the fused front end; 0: scores in */>
 __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     const bf16_t* __restrict__ score,      // [B][score_stride] (nullable: then cur_in is used)
     const int64_t* __restrict__ lm_idx,    // [B][N] slot -> chunk id (nullable: identity)
@@ -770,7 +1027,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     // [B][R], the S - cnt misses replace the least recently selected of the R - cnt slots that were not selected now
     // (age = steps since the slot's chunk was last selected, saturating at 62; 63 = empty slot; ties -> lowest slot).
     // R == S: every slot that was not selected is replaced, slot_age is not touched (may be null).
-    int R, int RP /* pow2 >= R */, int32_t* __restrict__ slot_age /* [B][R] */, EarlyHooks eh) {
+    int R, int RP /* pow2 >= R */, int32_t* __restrict__ slot_age /* [B][R] */, EarlyHooks eh, FusedTop ft) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_cur = s_hist + T2_BINS * T2_COPIES;        // [SP]   selected landmark slot per output position
@@ -783,11 +1040,14 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     int* s_rank = s_miss + SP;                        // [SP]
     int* s_w = s_rank + SP;                           // [4][16] wave totals (one row per block scan) + [16] wave maxima
     int* s_out = s_w + 80;                            // [16]
+    int* s_cand = s_out + 16;                         // [T3_CAND] candidate slots (fused front end)
+    float* s_fin = reinterpret_cast<float*>(s_cand + (FG > 0 ? T3_CAND : 0));   // [3 * FG] finals (m, 1 / s) and deltas
     const int tid = threadIdx.x;
     if (eh.staging != nullptr && (int)blockIdx.x >= (int)gridDim.x / (1 + eh.pull_wgs)) {
         // early fetch: the blocks behind the B selection blocks pull (skv_early.h)
         const int p = (int)blockIdx.x - (int)gridDim.x / (1 + eh.pull_wgs);
-        skv_early_pull_role<T2_THREADS>(eh, p / eh.pull_wgs, p % eh.pull_wgs, tid, smem);
+        if constexpr (FG > 0) skv_early_prep_pull_role<T2_THREADS>(eh, p / eh.pull_wgs, p % eh.pull_wgs, tid, smem);   // no normalise launch: list + pull
+        else skv_early_pull_role<T2_THREADS>(eh, p / eh.pull_wgs, p % eh.pull_wgs, tid, smem);
         return;
     }
     const int b = blockIdx.x;
@@ -845,11 +1105,17 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
                 w[i] = (j < N ? w[i] & 0xffffu : 0u) | (j + 1 < N ? w[i] & 0xffff0000u : 0u);
             }
         }
+        bool placed = false;
+        if constexpr (FG > 0)
+            placed = t3_fused_front<FG, NW>(w, ft, lm_idx, b, N, S, j0, tid, s_hist, s_w, s_out, s_cur, s_id, s_cand, s_fin, eh,
+                                            insert_resident);
+        if (!placed) {
         int thr, need_eq;
         t2_find_threshold<NW>(w, T2_THREADS * SEGV * 8 - N, S, tid, s_hist, s_w, s_out, thr, need_eq, insert_resident);
         if (eh.dthr_out != nullptr && tid < eh.G) {       // next step's flag thresholds (early fetch; prediction only)
             const float kth = __uint_as_float((uint32_t)thr << 16);
-            const float mx = eh.finals[((size_t)b * eh.G + tid) * 2], inv = eh.finals[((size_t)b * eh.G + tid) * 2 + 1];
+            const float* fin = FG > 0 ? s_fin : eh.finals + (size_t)b * eh.G * 2;
+            const float mx = fin[2 * tid], inv = fin[2 * tid + 1];
             eh.dthr_out[(size_t)b * eh.G + tid] = (kth > 0.f && inv > 0.f) ? mx + __logf(kth / inv) + eh.margin : INFINITY;
         }
         // ---- flags of the thread's keys as bit masks: bit 2i + h of word-group g <=> key (i, h) >= thr (mge) / > thr (mgt).
@@ -977,6 +1243,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
                 }
             }
         }
+        }   // !placed
         __syncthreads();                                   // (F)
         TOPK_STAMP(5);
         if (tid < S) {
@@ -1119,23 +1386,25 @@ static inline int next_pow2(int v) {
 
 template <int G>
 static int launch_score_g(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int N, int T,
-                          float alpha, hipStream_t st, const EarlyHooks& eh) {
+                          float alpha, hipStream_t st, const EarlyHooks& eh, const FusedSel& fs) {
     hipLaunchKernelGGL((skv_score_tile_kernel<G>), dim3(T, B), dim3(64 * (G == 8 ? 8 : SKV_SCORE_WAVES)), 0, st, (const bf16_t*)q,
-                       (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha, eh);
+                       (const bf16_t*)lm, (bf16_t*)D, pmax, psum, N, T, alpha, eh, fs);
     return SKV_OK;
 }
 
 int skv_launch_score(const void* q, const void* lm, void* D, float* pmax, float* psum, int B, int G, int N,
-                     float alpha, hipStream_t st, const EarlyHooks* hooks) {
+                     float alpha, hipStream_t st, const EarlyHooks* hooks, const FusedSel* fused) {
     const int T = (N + SKV_TILE - 1) / SKV_TILE;
     EarlyHooks eh{};
     if (hooks) eh = *hooks;
+    FusedSel fs{};
+    if (fused) fs = *fused;
     switch (G) {
-        case 1: return launch_score_g<1>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
-        case 2: return launch_score_g<2>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
-        case 4: return launch_score_g<4>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
-        case 8: return launch_score_g<8>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
-        case 16: return launch_score_g<16>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh);
+        case 1: return launch_score_g<1>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh, fs);
+        case 2: return launch_score_g<2>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh, fs);
+        case 4: return launch_score_g<4>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh, fs);
+        case 8: return launch_score_g<8>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh, fs);
+        case 16: return launch_score_g<16>(q, lm, D, pmax, psum, B, N, T, alpha, st, eh, fs);
         default: return SKV_ERR_UNSUPPORTED;
     }
 }
@@ -1177,27 +1446,35 @@ int skv_launch_normalize_groupmax(const void* D, const float* pmax, const float*
     return SKV_OK;
 }
 
-template <int SEGV>
+template <int SEGV, int FG>
 static int launch_topk2(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in, int64_t* cached,
                         int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots, int B, int N, int S, int H,
-                        int SP, int R, int RP, int32_t* slot_age, hipStream_t st, const EarlyHooks& eh) {
-    const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 5 + RP + H * 2 + 80 + 16) * sizeof(int);
+                        int SP, int R, int RP, int32_t* slot_age, hipStream_t st, const EarlyHooks& eh, const FusedTop& ft) {
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + SP * 5 + RP + H * 2 + 80 + 16 + (FG > 0 ? T3_CAND + 64 : 0)) * sizeof(int);
     static size_t attr_bytes[64] = {};
-    if (skv_ensure_max_lds((const void*)skv_topk2_kernel<SEGV>, (size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96) * sizeof(int),
-                           attr_bytes) != SKV_OK)
+    if (skv_ensure_max_lds((const void*)skv_topk2_kernel<SEGV, FG>,
+                           (size_t)(T2_BINS * T2_COPIES + 1024 * 6 + 4096 * 2 + 96 + (FG > 0 ? T3_CAND + 64 : 0)) * sizeof(int), attr_bytes) != SKV_OK)
         return SKV_ERR_LAUNCH;
     const bool pull = eh.staging != nullptr && eh.dthr_in != nullptr;
     EarlyHooks ek = eh;
     if (!pull) ek.staging = nullptr;
     ek.pull_wgs = B <= 8 ? SKV_EARLY_PULL_WGS : 1;
-    hipLaunchKernelGGL(skv_topk2_kernel<SEGV>, dim3(pull ? (1 + ek.pull_wgs) * B : B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
-                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age, ek);
+    if (pull && FG > 0 && skv_early_prep_lds_bytes(eh.n_chunks) + (EF_MAX_E + 1) * sizeof(int) > smem) return SKV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((skv_topk2_kernel<SEGV, FG>), dim3(pull ? (1 + ek.pull_wgs) * B : B), dim3(T2_THREADS), smem, st, (const bf16_t*)score, lm_idx, cur_in,
+                       cached, offsets, cnts, sel_out, dst_slots, N, score_stride, S, H, SP, R, RP, slot_age, ek, ft);
     return SKV_OK;
+}
+
+// shapes the fused selection front end is instantiated for (skv_launch_select_fused)
+bool skv_fused_select_supported(int G, int N, int S) {
+    const int per_thread = ((N + 7) / 8 + T2_THREADS - 1) / T2_THREADS;
+    return (G == 4 || G == 8) && per_thread <= 4 && (N + SKV_TILE - 1) / SKV_TILE <= 256 && S >= 1 && S <= N;
 }
 
 int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
-                            int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks) {
+                            int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks,
+                            const FusedTop* fused, int G) {
     if (S < 1 || S > SKV_SEL_THREADS || R < S || R > T2_THREADS) return SKV_ERR_UNSUPPORTED;
     EarlyHooks eh{};
     if (hooks) eh = *hooks;
@@ -1205,14 +1482,31 @@ int skv_launch_topk_resident(const void* score, int score_stride, const int64_t*
     if (R > S && (!dst_slots || !slot_age)) return SKV_ERR_ARG;      // a larger resident set exists in the in-place layout only
     const int SP = next_pow2(S), RP = next_pow2(R);
     const int H = 4 * RP;
+    FusedTop ft{};
+    if (fused) {                     // `score` = the scan launch's 15-bit keys; exact scores are computed from Dt in the kernel
+        if (!score || !fused->Dt || !fused->part_max || !fused->part_sum || !fused->ctil || !skv_fused_select_supported(G, N, S))
+            return SKV_ERR_UNSUPPORTED;
+        ft = *fused;
+        const int per_thread = (score_stride / 8 + T2_THREADS - 1) / T2_THREADS;
+#define SKV_T3(SV)                                                                                                      \
+    return G == 4 ? launch_topk2<SV, 4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, \
+                                        H, SP, R, RP, slot_age, st, eh, ft)                                             \
+                  : launch_topk2<SV, 8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, \
+                                        H, SP, R, RP, slot_age, st, eh, ft)
+        if (per_thread <= 1) { SKV_T3(1); }
+        if (per_thread <= 2) { SKV_T3(2); }
+        if (per_thread <= 4) { SKV_T3(4); }
+#undef SKV_T3
+        return SKV_ERR_UNSUPPORTED;
+    }
 #ifndef SKV_TOPK_V1
     {   // second-generation kernel: scores in registers, <= 16 vectors (128 scores) per thread
         const int per_thread = score ? (score_stride / 8 + T2_THREADS - 1) / T2_THREADS : 1;
-        if (per_thread <= 1) return launch_topk2<1>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
-        if (per_thread <= 2) return launch_topk2<2>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
-        if (per_thread <= 4) return launch_topk2<4>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
-        if (per_thread <= 8) return launch_topk2<8>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
-        if (per_thread <= 16) return launch_topk2<16>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh);
+        if (per_thread <= 1) return launch_topk2<1, 0>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh, ft);
+        if (per_thread <= 2) return launch_topk2<2, 0>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh, ft);
+        if (per_thread <= 4) return launch_topk2<4, 0>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh, ft);
+        if (per_thread <= 8) return launch_topk2<8, 0>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh, ft);
+        if (per_thread <= 16) return launch_topk2<16, 0>(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, H, SP, R, RP, slot_age, st, eh, ft);
     }
 #endif
     if (eh.dthr_in != nullptr) return SKV_ERR_UNSUPPORTED;   // early fetch: the pull role rides in the second-generation kernel
@@ -1240,5 +1534,5 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
                             int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
                             int B, int N, int S, hipStream_t st) {
     return skv_launch_topk_resident(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, S,
-                                    nullptr, st, nullptr);
+                                    nullptr, st, nullptr, nullptr, 0);
 }

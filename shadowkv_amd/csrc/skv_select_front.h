@@ -33,6 +33,25 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     return v;
 }
 
+// 15-bit order-preserving key of an f32 (x <= y  =>  key(x) <= key(y)): the ordered bit pattern - negative: ~bits, otherwise
+// bits | 0x80000000 - shifted down by 17 (sign, exponent, 6 mantissa bits: buckets 2^-6 wide relative).  skv_kappa_key_low(k) is
+// the SMALLEST f32 carrying key k, so "key(x) < k" implies "x < skv_kappa_key_low(k)" and "at least S keys >= k" implies "at least
+// S values >= skv_kappa_key_low(k)" - all the fused selection's exactness argument needs from the quantisation.
+__host__ __device__ __forceinline__ uint16_t skv_kappa_key(float x) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (uint16_t)(u >> 17);
+}
+__host__ __device__ __forceinline__ float skv_kappa_key_low(int key) {
+    uint32_t u = (uint32_t)key << 17;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+#define T3_CAND 2048                    // candidates the fused selection evaluates exactly on its fast path (two per thread)
+
 #define T2_THREADS 1024
 #define T2_BINS 4096
 #define T2_COPIES 4
