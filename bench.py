@@ -105,6 +105,8 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
         llama.build_synthetic_context_full(model, ctx, seed=4321 + 100 * rank)
     else:
         llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
+    if not full:
+        model.kv_cache.fused_select = bool(getattr(args, "fused_select", 1))
     if (not full and args.early_fetch and args.v_table == "host" and model.kv_cache.early_fetch_supported()
             and model.kv_cache.select_sets >= 128 and (args.batch == 1 or args.early_fetch_batches)):
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
@@ -247,10 +249,19 @@ def measure_score_kernel(model, iters=3):
     L = _lib.lib()
 
     ea = getattr(cache, "_early", None)
+    fused = bool(getattr(cache, "fused_select", False) and getattr(cache, "_sel_state", None) is not None
+                 and L.skv_select_fused_supported(G, N, cache.select_sets))
+    ws = torch.empty(L.skv_select_workspace_bytes(B, G, N), dtype=torch.uint8, device=dev) if fused else None
+    sel_state = torch.zeros_like(cache._sel_state) if fused else None      # (a copy: the measurement must not move the step's state)
 
     def run_all():
         for l in range(model.num_layers):
-            if ea is not None:      # the scan as the step launches it: with the early fetch's flag pass
+            if fused:               # the scan as the step launches it: keys + slot-major logits (+ the early fetch's flag pass)
+                _lib.check(L.skv_score_landmarks_fused(q.data_ptr(), cache.k_landmark[l].data_ptr(), cache.k_landmark_idx[l].data_ptr(),
+                                                       ws.data_ptr(), B, G, N, 1.0 / math.sqrt(128), sel_state[l].data_ptr(),
+                                                       0 if ea is None else ea["states"][l].data_ptr(), 0 if ea is None else ea["n_chunks"],
+                                                       0 if ea is None else ea["E"], st), "score")
+            elif ea is not None:      # the scan as the step launches it: with the early fetch's flag pass
                 _lib.check(L.skv_score_landmarks_early(q.data_ptr(), cache.k_landmark[l].data_ptr(),
                                                        cache.k_landmark_idx[l].data_ptr(), D.data_ptr(), pm.data_ptr(),
                                                        ps.data_ptr(), B, G, N, 1.0 / math.sqrt(128),
@@ -269,7 +280,7 @@ def measure_score_kernel(model, iters=3):
     us = e0.elapsed_time(e1) * 1e3 / (iters * model.num_layers)
     alg_bytes = B * N * 128 * 2            # landmark rows read once (SURVEY.md 8d "landmark read")
     return dict(kernel="skv_score_tile_kernel", us_per_launch=us, algorithmic_bytes=alg_bytes,
-                gbs=alg_bytes / us * 1e-3)
+                gbs=alg_bytes / us * 1e-3, launch="fused selection (keys + slot-major logits)" if fused else "three-launch selection")
 
 
 def measure_path_only(model, walk_step, steps=8):
@@ -742,6 +753,9 @@ def main(argv=None):
     ap.add_argument("--no-step-sync", action="store_true",
                     help="diagnostic: do not read the token back every step (the reference's loop does, base.py:635, and so does "
                          "every reported number)")
+    ap.add_argument("--fused-select", type=int, default=1, choices=[0, 1],
+                    help="1 (default): selection as scan -> top-k with the logit-domain prefilter (two launches, identical results); "
+                         "0: score -> normalise -> top-k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
@@ -897,7 +911,7 @@ def main(argv=None):
             out["roofline"] = {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; collected by tools/pmc_score.sh in round 3, a separate profiled run - not re-measured inside this run)",
-                               "kernel": roof["kernel"], "us_per_launch": round(roof["us_per_launch"], 3),
+                               "kernel": roof["kernel"], "launch_form": roof.get("launch"), "us_per_launch": round(roof["us_per_launch"], 3),
                                "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
         out.update(extras)
         if bs == 24 and args.workload == "llama31_122k" and not full:

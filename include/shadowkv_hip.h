@@ -341,6 +341,32 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
                               long long cache_stride_s, int sparse_start, int rope_mode, long long host_block_stride,
                               int attn_splits, int resident_sets, float scale, skv_stream_t stream);
 
+/* ---- fused selection (round 4): two launches instead of three -------------------------------------------------------
+ * skv_select_chunks / skv_select_chunks_inplace[_early] without the normalise launch: the scan launch also leaves, per
+ * landmark slot, a 15-bit monotone key of max_g (logit_g - c~_g) - the group maximum in the logit domain under the PREVIOUS
+ * step's log-normalisers c~_g = m_g + ln s_g, kept in select_state - and the top-k launch (1) computes this step's softmax
+ * finals from the tile partials, (2) takes as candidates every slot whose key reaches key(S-th largest kappa - spread of
+ * (c_g - c~_g) - 2^-4) - every other slot's score is strictly below S slots' scores, (3) evaluates the candidates' scores
+ * EXACTLY (the normalise kernel's arithmetic) and (4) selects the exact top-S among them with the usual tie rule and diff.
+ * A step with more than 2,048 candidates (first step, a jump of the query) evaluates every slot in the same launch.  Results are
+ * IDENTICAL to the three-launch entries (same selected set, same reordering / miss lists / hit counts).  The reference has no
+ * counterpart (three CUTLASS kernels + torch.max / topk / gather, /root/reference/models/kv_cache.py:1006-1042).
+ * dst_slots null: the reference's slot order (cached_pos_ids reordered in place, miss_ids = offsets); non-null: in-place layout.
+ * select_state: skv_select_state_bytes(blocks, groups) bytes of device memory PER LAYER, zeroed once (skv_select_state_init).
+ * early_state (nullable) + v_host .. margin: the speculative early V fetch as in skv_select_chunks_inplace_early; its list role
+ * then runs in the pull workgroups of the top-k launch.  groups in {4, 8}, n_landmarks <= 32,768: skv_select_fused_supported. */
+SKV_EXPORT int skv_select_fused_supported(int groups, int n_landmarks, int select_sets);
+SKV_EXPORT size_t skv_select_state_bytes(int blocks, int groups);
+SKV_EXPORT int skv_select_state_init(void* state, int blocks, int groups, skv_stream_t stream);
+SKV_EXPORT int skv_score_landmarks_fused(const void* q, const void* landmarks, const int64_t* landmark_idx, void* workspace, int blocks,
+                              int groups, int n_landmarks, float alpha, void* select_state, void* early_state, int n_chunks,
+                              int early_max, skv_stream_t stream);   /* the scan launch of skv_select_chunks_fused alone (measurement) */
+SKV_EXPORT int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                            int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts, void* workspace, int64_t* selected_out,
+                            int blocks, int groups, int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age,
+                            float alpha, void* select_state, void* early_state, const void* v_host, long long host_block_stride,
+                            int n_chunks, int early_max, float margin, skv_stream_t stream);
+
 /* ---- speculative early V fetch (in-place layout) -------------------------------------------------------------------
  * Which chunks a step will MISS is predictable as soon as the scan has produced the logits: a landmark slot whose logit
  * reaches the previous step's k-th value (in logit space, per query head) and whose chunk is not resident.  With an early

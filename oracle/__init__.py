@@ -71,6 +71,17 @@ def group_max_topk(P, landmark_idx, blocks, groups, n, topk):
     return out
 
 
+def fused_candidates(D, fin_m, fin_inv, ctil, topk):
+    """Candidate rule of the device's fused selection (oracle_fused_candidates): D bf16 [blocks, groups, n] logits, fin_m /
+    fin_inv f32 [blocks, groups] softmax finals, ctil f32 [blocks, groups] -> (mask uint8 [blocks, n], counts int32 [blocks])."""
+    blocks, groups, n = D.shape
+    mask = torch.empty(blocks, n, dtype=torch.uint8)
+    counts = torch.empty(blocks, dtype=torch.int32)
+    lib().oracle_fused_candidates(_p(D), _p(fin_m.contiguous()), _p(fin_inv.contiguous()), _p(ctil.contiguous()), _i(blocks),
+                                  _i(groups), _i(n), _i(topk), _p(mask), _p(counts))
+    return mask, counts
+
+
 def reorder_keys_and_compute_offsets(cached_pos_ids, cur_pos_ids, offsets, cnts, batch_size, heads, map_size):
     assert cached_pos_ids.dtype == torch.int64 and cur_pos_ids.dtype == torch.int64
     assert offsets.dtype == torch.int32 and cnts.dtype == torch.int32

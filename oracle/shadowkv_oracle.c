@@ -525,6 +525,77 @@ ORACLE_API void oracle_rope_new(const uint16_t *x, const uint16_t *cos_sin,
 }
 
 /* ------------------------------------------------------------------------- */
+/* a4 + a5, fused selection (round 4): the candidate rule, restated          */
+/* ------------------------------------------------------------------------- */
+/* The device's fused selection (csrc/skv_select.hip, t3_fused_front) drops the normalise launch: the scan leaves a 15-bit
+ * monotone key of kappa_j = min(max_g (D_gj - ctil_g), -2^-12) per slot (ctil = the previous step's log-normalisers), the
+ * top-k launch computes this step's finals (m_g, 1 / s_g), takes as CANDIDATES every slot with
+ *      key(kappa_j) >= min( key(theta), k15 ),   theta = low(k15) - (max_g delta_g - min_g delta_g) - 2^-4,
+ * k15 = the S-th largest key, low(k) = the smallest f32 with key k, delta_g = (m_g + ln s_g) - ctil_g, evaluates the
+ * candidates' scores exactly and selects the exact top S among them.  Why no other slot can be in the top S or tie with its
+ * last member (the argument in full: skv_select.hip): with K_j = max_g (D_gj - c_g), c_g = m_g + ln s_g, one has
+ * kappa_j - max delta <= K_j <= kappa_j - min delta (the clamp only lowers kappa of slots whose K is <= 0 anyway and keeps the
+ * map monotone); S slots a have kappa_a >= low(k15); key(kappa_j) < key(theta) implies kappa_j < theta, hence
+ * K_j < K_a - 2^-4 for those S slots, and score = max_g bf16(exp(D - m_g) / s_g) ~ exp(K) (relative 2^-9 + ~2e-6) is then
+ * strictly smaller: e^(-1/16) (1 + 2^-9 + 2e-6) < 1 - 2^-9 - 2e-6.
+ * This function restates the rule on the CPU (keys, S-th key by sorting, ln in double): tests/test_oracle_golden.py checks on
+ * every fixture and on adversarial inputs that the oracle's exact top-S (oracle_group_max_topk over the exact scores) lies
+ * inside the candidate set for ANY ctil - zero, exact, perturbed, garbage -, which is all the device needs for identical
+ * results.  D [B][G][N] bf16 logits; fin_m / fin_inv [B][G] the finals; ctil [B][G]; cand [B][N] out (1 = candidate);
+ * counts [B] out. */
+static uint16_t kappa_key(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (uint16_t)(u >> 17);
+}
+static float kappa_key_low(int key) {
+    uint32_t u = (uint32_t)key << 17;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+static int cmp_u16_desc(const void *a, const void *b) { return (int)*(const uint16_t *)b - (int)*(const uint16_t *)a; }
+
+ORACLE_API void oracle_fused_candidates(const uint16_t *D, const float *fin_m, const float *fin_inv, const float *ctil,
+                                        int blocks, int groups, int n, int topk, uint8_t *cand, int32_t *counts) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < blocks; ++b) {
+        uint16_t *key = (uint16_t *)malloc((size_t)n * 2), *srt = (uint16_t *)malloc((size_t)n * 2);
+        for (int j = 0; j < n; ++j) {
+            float kap = -INFINITY;
+            for (int g = 0; g < groups; ++g) {
+                float v = bf2f(D[((size_t)b * groups + g) * n + j]) - ctil[b * groups + g];
+                if (v > kap) kap = v;
+            }
+            if (kap > -0x1p-12f) kap = -0x1p-12f;
+            key[j] = srt[j] = kappa_key(kap);
+        }
+        qsort(srt, (size_t)n, 2, cmp_u16_desc);
+        int k15 = srt[topk - 1];
+        double dmax = -1e300, dmin = 1e300;
+        for (int g = 0; g < groups; ++g) {
+            double c = (double)fin_m[b * groups + g] - log((double)fin_inv[b * groups + g]);
+            double d = c - (double)ctil[b * groups + g];
+            if (d > dmax) dmax = d;
+            if (d < dmin) dmin = d;
+        }
+        float theta = (float)((double)kappa_key_low(k15) - (dmax - dmin) - 0.0625);
+        int thr_lo = theta == theta ? (int)kappa_key(theta) : 0;
+        if (thr_lo > k15) thr_lo = k15;
+        int c = 0;
+        for (int j = 0; j < n; ++j) {
+            cand[(size_t)b * n + j] = key[j] >= thr_lo;
+            c += key[j] >= thr_lo;
+        }
+        counts[b] = c;
+        free(key);
+        free(srt);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* a11: sparse attention over the assembled buffers (models/base.py:341)     */
 /* ------------------------------------------------------------------------- */
 /* q [bs][q_heads][D] bf16 (q_len = 1), k/v [bs][kv_heads][kv_stride rows][D]

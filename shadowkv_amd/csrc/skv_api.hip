@@ -19,7 +19,9 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
                             int B, int N, int S, hipStream_t st);
 int skv_launch_topk_resident(const void* score, int score_stride, const int64_t* lm_idx, const int64_t* cur_in,
                              int64_t* cached, int32_t* offsets, int32_t* cnts, int64_t* sel_out, int32_t* dst_slots,
-                             int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks = nullptr);
+                             int B, int N, int S, int R, int32_t* slot_age, hipStream_t st, const EarlyHooks* hooks = nullptr,
+                             const FusedTop* fused = nullptr, int G = 0);
+bool skv_fused_select_supported(int G, int N, int S);
 int skv_launch_early_init(const EarlyState& es, int B, int G, int n_landmarks, int n_chunks, int E, hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, void* temp, const int32_t* offsets, const int32_t* cnts,
                          long long host_len_elems, long long dev_stride_elems, long long dev_off_elems, int B, int S,
@@ -346,6 +348,52 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
                                            st, &eh));
 }
 
+// ---- fused selection (round 4): scan (+ keys, slot-major logits) -> top-k with the logit-domain prefilter; no normalise launch
+int skv_select_fused_supported(int groups, int n_landmarks, int select_sets) {
+    return skv_fused_select_supported(groups, n_landmarks, select_sets) ? 1 : 0;
+}
+
+size_t skv_select_state_bytes(int blocks, int groups) {
+    return blocks < 1 || groups < 1 ? 0 : align256((size_t)blocks * groups * sizeof(float));
+}
+
+int skv_select_state_init(void* state, int blocks, int groups, skv_stream_t stream) {
+    if (!state || blocks < 1 || groups < 1) return SKV_ERR_ARG;
+    return hipMemsetAsync(state, 0, skv_select_state_bytes(blocks, groups), (hipStream_t)stream) == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+}
+
+int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
+                            int32_t* miss_ids, int32_t* dst_slots, int32_t* cnts, void* workspace, int64_t* selected_out,
+                            int blocks, int groups, int n_landmarks, int select_sets, int resident_sets, int32_t* slot_age,
+                            float alpha, void* select_state, void* early_state, const void* v_host, long long host_block_stride,
+                            int n_chunks, int early_max, float margin, skv_stream_t stream) {
+    if (!q || !landmarks || !cached_pos_ids || !miss_ids || !cnts || !workspace || !select_state) return SKV_ERR_ARG;
+    if (blocks < 1 || n_landmarks < select_sets || select_sets < 1 || resident_sets < select_sets) return SKV_ERR_ARG;
+    if (!dst_slots && resident_sets != select_sets) return SKV_ERR_ARG;       // a larger resident set: in-place layout only
+    if (!skv_fused_select_supported(groups, n_landmarks, select_sets)) return SKV_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    // the workspace's logit region holds the slot-major logits, its score region the 15-bit keys
+    FusedSel fs{(const float*)select_state, (uint16_t*)w.score, w.D, w.score_stride};
+    FusedTop ft{w.D, w.pmax, w.psum, (float*)select_state, (n_landmarks + 255) / 256};
+    EarlyHooks eh{};
+    const EarlyHooks* hooks = nullptr;
+    if (early_state) {
+        if (!landmark_idx || !v_host || (host_block_stride % 8) || n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
+        if (n_landmarks > 65536 || resident_sets > 1024 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
+        const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+        eh = EarlyHooks{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
+                        es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
+                        (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
+        hooks = &eh;
+    }
+    int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, hooks, &fs);
+    if (rc != SKV_OK) return rc;
+    return finish(skv_launch_topk_resident(w.score, w.score_stride, landmark_idx, nullptr, cached_pos_ids, miss_ids, cnts,
+                                           selected_out, dst_slots, blocks, n_landmarks, select_sets, resident_sets, slot_age, st,
+                                           hooks, &ft, groups));
+}
+
 // reference slot order (skv_select_chunks / skv_fetch_kv) with the early fetch
 int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t* landmark_idx, int64_t* cached_pos_ids,
                             int32_t* offsets, int32_t* cnts, void* workspace, void* softmax_out, int64_t* selected_out,
@@ -421,6 +469,25 @@ int skv_score_landmarks_early(const void* q, const void* landmarks, const int64_
     eh.T = (n_landmarks + 255) / 256; eh.N = n_landmarks; eh.n_chunks = n_chunks; eh.E = early_max;
     return finish(skv_launch_score(q, landmarks, logits, part_max, part_sum, blocks, groups, n_landmarks, alpha,
                                    (hipStream_t)stream, &eh));
+}
+
+/* the scan launch exactly as skv_select_chunks_fused issues it (measurement: bench.py's roofline of the dominant kernel) */
+int skv_score_landmarks_fused(const void* q, const void* landmarks, const int64_t* landmark_idx, void* workspace, int blocks,
+                              int groups, int n_landmarks, float alpha, void* select_state, void* early_state, int n_chunks,
+                              int early_max, skv_stream_t stream) {
+    if (!q || !landmarks || !workspace || !select_state || blocks < 1 || n_landmarks < 1) return SKV_ERR_ARG;
+    if (!skv_fused_select_supported(groups, n_landmarks, 1)) return SKV_ERR_UNSUPPORTED;
+    SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
+    FusedSel fs{(const float*)select_state, (uint16_t*)w.score, w.D, w.score_stride};
+    EarlyHooks eh{};
+    if (early_state) {
+        if (!landmark_idx || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+        const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+        eh.dthr_in = es.dthr; eh.flag_cnt = es.flag_cnt; eh.flag_slot = es.flag_slot; eh.G = groups; eh.lm_idx = landmark_idx;
+        eh.T = (n_landmarks + 255) / 256; eh.N = n_landmarks; eh.n_chunks = n_chunks; eh.E = early_max;
+    }
+    return finish(skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, (hipStream_t)stream,
+                                   early_state ? &eh : nullptr, &fs));
 }
 
 int skv_rebuild_keys(const void* U, const void* SV, const void* cos_sin, const int64_t* chunk_ids,

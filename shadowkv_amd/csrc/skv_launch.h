@@ -39,6 +39,15 @@ struct FusedSel {
     int key_stride;
 };
 
+// the top-k launch's side of it
+struct FusedTop {
+    const void* Dt;           // [B][N][G] bf16 (scan launch, FusedSel); null = scores in (three-launch path)
+    const float* part_max;    // [B][T][G]
+    const float* part_sum;
+    float* ctil;              // [B][G] in: what the scan's keys were taken against; out: this step's c_g
+    int T;
+};
+
 // Hooks of the speculative early V fetch in the selection launches (skv_select.hip, roles in skv_early.h); dthr_in null = off.
 //   scan:      a landmark slot whose logit reaches dthr_in[b][g] for some query head g is FLAGGED (it would have made the
 //              previous step's top-k): per tile the first SKV_EARLY_K flagged slots go to flag_slot, their number to flag_cnt.

@@ -794,14 +794,6 @@ __global__ __launch_bounds__(SKV_SEL_THREADS) void skv_topk_reorder_kernel(
 // (oracle_fused_candidates) restates the candidate rule and the tests check top-S subset-of candidates on every input.
 // Returns true when s_cur / s_id hold the selection; false: w[] holds the exact score keys (padding 0), histogram zeroed.
 // ---------------------------------------------------------------------------------------
-struct FusedTop {
-    const void* Dt;           // [B][N][G] bf16 (scan launch, FusedSel); null = scores in (three-launch path)
-    const float* part_max;    // [B][T][G]
-    const float* part_sum;
-    float* ctil;              // [B][G] in: what the scan's keys were taken against; out: this step's c_g
-    int T;
-};
-
 template <int FG>
 __device__ __forceinline__ uint32_t t3_exact_key(const bf16_t* __restrict__ drow, const float* s_fin) {
     bf16_t d[FG];

@@ -231,6 +231,11 @@ class ShadowKVCache_CPU:
         self._dst_slots = None           # in-place layout: destination slot per miss (select_fetch_inplace)
         self._early = None               # speculative early V fetch (enable_early_fetch): per-layer states
         self._early_request = None       # (early_max, margin) to re-enable with after clear() + a new prefill (H2D)
+        # Fused selection (round 4, csrc/skv_select.hip t3_fused_front): scan -> top-k without the normalise launch, identical
+        # results; per-layer state = the log-normalisers the next step's scan takes its keys against.  Shapes the kernels are
+        # not instantiated for (G not in {4, 8}, more than 32,768 landmarks per head) keep the three-launch path.
+        self.fused_select = True
+        self._sel_state = None
         self._pushed = None              # rows the host model's RoPE launch has already pushed (note_rows_pushed)
         # Reference call order (get_value_cache under copy_stream, then get_key_cache, base.py:326-338): with this flag
         # get_value_cache only returns its view and the get_key_cache call that follows for the same layer moves K AND V
@@ -297,6 +302,9 @@ class ShadowKVCache_CPU:
             n = self.k_landmark.shape[-2]
             nbytes = lib().skv_select_workspace_bytes(self.block_num, self.num_key_value_groups, n)
             self._select_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            sb = int(lib().skv_select_state_bytes(self.block_num, self.num_key_value_groups))
+            if self._sel_state is None or self._sel_state.shape[1] != sb:
+                self._sel_state = torch.zeros(self.num_layers, sb, dtype=torch.uint8, device=self.device)
             torch.cuda.synchronize(self.device)
             req = getattr(self, "_early_request", None)
             if req is not None and self._early is None and self.prefilled_batch == self.batch_size \
@@ -471,26 +479,56 @@ class ShadowKVCache_CPU:
         if self._select_ws is None:
             self.H2D()
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
-        ea = self._early_state()
+        # early fetch in the reference's slot order: only when its consumer (fetch_kv - reached through the deferred
+        # get_value_cache + get_key_cache pair, or called next by the fused step, which says so with fetch_kv_follows)
+        # follows; the plain mover ignores the staging buffer
         self._early_pub = None
-        if ea is not None and (self.lazy_value_fetch or self.fetch_kv_follows):
-            # early fetch in the reference's slot order: only when its consumer (fetch_kv - reached through the deferred
-            # get_value_cache + get_key_cache pair, or called next by the fused step, which says so with fetch_kv_follows)
-            # follows; the plain mover ignores the staging buffer
-            vhost = self.v_cache_cpu[layer_idx]
-            check(lib().skv_select_chunks_early(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
-                                                ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
-                                                self.select_sets, 1.0 / math.sqrt(128), ptr(ea["states"][layer_idx]),
-                                                ptr(vhost), vhost.stride(1), ea["n_chunks"], ea["E"], ea["margin"],
-                                                current_stream_handle()), "get_retrieval_position_ids (early)")
+        if self._select_native(layer_idx, q, inplace=False, early_ok=bool(self.lazy_value_fetch or self.fetch_kv_follows)):
             self._early_pub = layer_idx
-        else:
-            check(lib().skv_select_chunks(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
-                                          ptr(self._select_ws), 0, 0, self.block_num, self.num_key_value_groups, n,
-                                          self.select_sets, 1.0 / math.sqrt(128), current_stream_handle()),
-                  "get_retrieval_position_ids")
         self._stage_hits(layer_idx)
         return lv.pos
+
+    def _select_native(self, layer_idx, q, inplace, early_ok=True):
+        """The selection launches of one layer (score -> [normalise] -> top-k + diff) on the current stream: the fused two-launch
+        form where the kernels take the shape (skv_select_chunks_fused), else the three-launch entries.  inplace: hits keep their
+        slots (offsets = miss ids, _dst_slots); else the reference's slot order.  Returns True when an early-fetch list was
+        published (its consumer must be one of the *_early fetch launches of this layer)."""
+        L, st = lib(), current_stream_handle()
+        lv = self._layer(layer_idx)
+        lm, n = lv.lm, lv.lm.shape[-2]
+        ea = self._early_state() if early_ok else None
+        vhost = lv.vhost
+        alpha = 1.0 / math.sqrt(128)
+        G, S, R = self.num_key_value_groups, self.select_sets, self.resident_sets
+        if inplace and self._dst_slots is None:
+            self._dst_slots = torch.zeros_like(self.offsets)
+        if self.fused_select and self._sel_state is not None and L.skv_select_fused_supported(G, n, S):
+            check(L.skv_select_chunks_fused(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets),
+                                            ptr(self._dst_slots) if inplace else 0, ptr(self.cnts), ptr(self._select_ws), 0,
+                                            self.block_num, G, n, S, R if inplace else S, ptr(lv.age) if inplace else 0, alpha,
+                                            ptr(self._sel_state[layer_idx]), 0 if ea is None else ptr(ea["states"][layer_idx]),
+                                            ptr(vhost), vhost.stride(1), 0 if ea is None else ea["n_chunks"],
+                                            0 if ea is None else ea["E"], 0.0 if ea is None else ea["margin"], st),
+                  "select_chunks_fused")
+            return ea is not None
+        if inplace:
+            sel_args = (ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self._dst_slots), ptr(self.cnts),
+                        ptr(self._select_ws), 0, 0, self.block_num, G, n, S, R, ptr(lv.age), alpha)
+            if ea is not None:
+                check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
+                                                        ea["n_chunks"], ea["E"], ea["margin"], st), "select_chunks_inplace_early")
+            else:
+                check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
+            return ea is not None
+        if ea is not None:
+            check(L.skv_select_chunks_early(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
+                                            ptr(self._select_ws), 0, 0, self.block_num, G, n, S, alpha, ptr(ea["states"][layer_idx]),
+                                            ptr(vhost), vhost.stride(1), ea["n_chunks"], ea["E"], ea["margin"], st),
+                  "get_retrieval_position_ids (early)")
+            return True
+        check(L.skv_select_chunks(ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self.cnts),
+                                  ptr(self._select_ws), 0, 0, self.block_num, G, n, S, alpha, st), "get_retrieval_position_ids")
+        return False
 
     def _reference_layout_only(self, what):
         if self.resident_sets != self.select_sets:
@@ -609,19 +647,7 @@ class ShadowKVCache_CPU:
         if self._dst_slots is None:
             self._dst_slots = torch.zeros_like(self.offsets)
         q = query_states if query_states.is_contiguous() else query_states.contiguous()
-        L, st = lib(), current_stream_handle()
-        vhost = self.v_cache_cpu[layer_idx]
-        sel_args = (ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
-                    ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
-                    ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
-                    self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                    self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
-        ea = self._early_state()
-        if ea is not None:
-            check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
-                                                    ea["n_chunks"], ea["E"], ea["margin"], st), "select_chunks_inplace_early")
-        else:
-            check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
+        self._select_native(layer_idx, q, inplace=True)
 
     def _fetch_inplace(self, layer_idx, cos_sin_cache):
         L, st = lib(), current_stream_handle()
@@ -803,18 +829,8 @@ class ShadowKVCache_CPU:
         ws = tensor_op.attention_workspace(q.device, bs, Hq, SA + self.select_sets // 8)
         kbuf, vbuf = self.k_cache_buffer[layer_idx], self.v_cache_buffer[layer_idx]
         vhost = self.v_cache_cpu[layer_idx]
-        sel_args = (ptr(q), ptr(lm), ptr(self.k_landmark_idx[layer_idx]),
-                    ptr(self.position_ids[layer_idx]), ptr(self.offsets), ptr(self._dst_slots),
-                    ptr(self.cnts), ptr(self._select_ws), 0, 0, self.block_num,
-                    self.num_key_value_groups, lm.shape[-2], self.select_sets,
-                    self.resident_sets, ptr(self._slot_age[layer_idx]), 1.0 / math.sqrt(128))
+        self._select_native(layer_idx, q, inplace=True)
         ea = self._early_state()
-        if ea is not None:
-            check(L.skv_select_chunks_inplace_early(*sel_args, ptr(ea["states"][layer_idx]), ptr(vhost), vhost.stride(1),
-                                                    ea["n_chunks"], ea["E"], ea["margin"], st),
-                  "select_chunks_inplace_early")
-        else:
-            check(L.skv_select_chunks_inplace(*sel_args, st), "select_chunks_inplace")
         U, SV = self.U[layer_idx], self.SV[layer_idx]
         width = cos_sin_cache.shape[-1]
         scale = 1.0 / math.sqrt(D)

@@ -410,3 +410,104 @@ def test_sparse_attention(bs, Hq, Hkv, kv_len, splits):
     torch.cuda.synchronize()
     check_attention(f"test_sparse_attention[{bs}-{Hq}-{Hkv}-{kv_len}-{splits}] clamped", out.cpu().float(), q, k, v, rows, scale,
                     standalone_pass_labels(bs, Hq, Hkv, rows, splits))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused selection (round 4): scan -> top-k with the logit-domain prefilter, no normalise launch
+# ----------------------------------------------------------------------------------------------------------------------
+def _fused_case_inputs(blocks, G, N, kind, g):
+    lm = torch.randn(blocks, N, 128, generator=g).bfloat16()
+    if kind == "ties":
+        lm[:, N // 8: N // 8 + 600] = lm[:, N // 8: N // 8 + 1]       # 600 identical landmarks: identical logits, tied bf16 scores
+    if kind == "flat":
+        lm[:] = lm[:, :1]                                             # every slot ties: the selection is the tie rule alone
+    if kind == "runs":                                                # attention locality: the high scores sit in runs of neighbours
+        base = torch.randn(blocks, 1, 128, generator=g)
+        for b in range(blocks):
+            for _ in range(12):
+                st = int(torch.randint(0, N - 40, (1,), generator=g))
+                lm[b, st:st + 32] = (base[b] * 2.0 + 0.3 * torch.randn(32, 128, generator=g)).bfloat16()
+    lm_idx = torch.stack([torch.sort(torch.randperm(N + 48, generator=g)[:N]).values for _ in range(blocks)]).to(torch.int64)
+    return lm, lm_idx
+
+
+@pytest.mark.parametrize("blocks,G,N,S,kind,inplace", [
+    (8, 4, 15560, 256, "walk", True),        # headline shape (2 key vectors per thread)
+    (8, 4, 15560, 256, "walk", False),       # ... in the reference's slot order
+    (4, 8, 25544, 256, "walk", True),        # GLM-4 / Yi-9B: G = 8, 4 key vectors per thread
+    (2, 4, 31128, 512, "walk", True),        # budget 4096 at 244K
+    (2, 4, 7500, 128, "walk", True),         # budget 1024 at 60K (1 key vector per thread)
+    (3, 8, 777, 32, "walk", False),          # row shorter than the workgroup, N % 8 != 0
+    (2, 4, 5000, 256, "ties", True),         # the k-th score tied hundreds of times: ties -> lowest slot
+    (2, 8, 3000, 256, "flat", True),         # every slot a candidate: more than 2,048 -> every slot evaluated in the launch
+    (4, 4, 15560, 256, "runs", True),        # a thread owns a run of candidates
+    (2, 4, 9000, 256, "jump", True),         # a new query every step: the previous normalisers are useless
+    (2, 4, 9000, 256, "garbage", False),     # the state holds garbage (+-1e3, inf): any finite or infinite value is valid input
+])
+def test_fused_selection_equals_the_three_launch_path(blocks, G, N, S, kind, inplace):
+    """skv_select_chunks_fused against skv_select_chunks[_inplace] fed the same queries from the same resident set, step by
+    step: selected ids, reordered / in-place resident ids, miss lists, destination slots and hit counts bit for bit - on the
+    first step (normalisers 0: every slot is evaluated), on steps with good normalisers (fast path: S plus a few dozen
+    candidates), on ties, on an all-equal row, after query jumps and with garbage in the state."""
+    L = _lib()
+    g = torch.Generator().manual_seed(11 * N + S + G)
+    lm, lm_idx = _fused_case_inputs(blocks, G, N, kind, g)
+    assert L.lib().skv_select_fused_supported(G, N, S) == 1
+    lmd, lid = lm.to(DEV), lm_idx.to(DEV)
+    ws_a = torch.empty(L.lib().skv_select_workspace_bytes(blocks, G, N), dtype=torch.uint8, device=DEV)
+    ws_b = torch.empty_like(ws_a)
+    state = torch.zeros(L.lib().skv_select_state_bytes(blocks, G), dtype=torch.uint8, device=DEV)
+    L.check(L.lib().skv_select_state_init(state.data_ptr(), blocks, G, _stream()), "select_state_init")
+    cached0 = torch.stack([lm_idx[b][torch.randperm(N, generator=g)[:S]] for b in range(blocks)])
+    ca, cb = cached0.to(DEV), cached0.to(DEV)
+
+    def bufs():
+        return (torch.full((blocks, S), -7, dtype=torch.int32, device=DEV), torch.full((blocks, S), -7, dtype=torch.int32, device=DEV),
+                torch.zeros(blocks, dtype=torch.int32, device=DEV), torch.zeros(blocks, S, dtype=torch.int64, device=DEV))
+    q32 = torch.randn(blocks, G, 128, generator=g) * 2.0
+    for step in range(7):
+        if kind == "jump" or step == 4:
+            q32 = torch.randn(blocks, G, 128, generator=g) * (2.0 if step != 4 else 3.5)     # (step 4: a jump in every case)
+        else:
+            q32 = q32 + 0.3 * torch.randn(blocks, G, 128, generator=g)
+        if kind == "garbage" and step in (2, 5):
+            junk = torch.randn(blocks * G, generator=g) * 1e3
+            junk[0] = float("inf"); junk[1] = float("-inf")
+            state.view(torch.float32)[:blocks * G].copy_(junk)
+        qd = q32.bfloat16().to(DEV)
+        ma, sa, na, oa = bufs()
+        mb, sb, nb, ob = bufs()
+        if inplace:
+            L.check(L.lib().skv_select_chunks_inplace(qd.data_ptr(), lmd.data_ptr(), lid.data_ptr(), ca.data_ptr(), ma.data_ptr(),
+                                                      sa.data_ptr(), na.data_ptr(), ws_a.data_ptr(), 0, oa.data_ptr(), blocks, G, N,
+                                                      S, S, 0, ALPHA, _stream()), "select_chunks_inplace")
+        else:
+            L.check(L.lib().skv_select_chunks(qd.data_ptr(), lmd.data_ptr(), lid.data_ptr(), ca.data_ptr(), ma.data_ptr(),
+                                              na.data_ptr(), ws_a.data_ptr(), 0, oa.data_ptr(), blocks, G, N, S, ALPHA, _stream()),
+                    "select_chunks")
+        L.check(L.lib().skv_select_chunks_fused(qd.data_ptr(), lmd.data_ptr(), lid.data_ptr(), cb.data_ptr(), mb.data_ptr(),
+                                                sb.data_ptr() if inplace else 0, nb.data_ptr(), ws_b.data_ptr(), ob.data_ptr(),
+                                                blocks, G, N, S, S, 0, ALPHA, state.data_ptr(), 0, 0, 0, 0, 0, 0.0, _stream()),
+                "select_chunks_fused")
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob), f"{kind} step {step}: selected ids"
+        assert torch.equal(na, nb), f"{kind} step {step}: hit counts"
+        assert torch.equal(ca, cb), f"{kind} step {step}: resident ids"
+        assert torch.equal(ma, mb), f"{kind} step {step}: offsets / miss ids"
+        if inplace:
+            assert torch.equal(sa, sb), f"{kind} step {step}: destination slots"
+        st = state.view(torch.float32)[:blocks * G]
+        assert bool(torch.isfinite(st).all()), "the state the launch leaves behind is this step's log-normalisers"
+    if kind == "flat":
+        slot_of = [{int(c): j for j, c in enumerate(lm_idx[b].tolist())} for b in range(blocks)]
+        for b in range(blocks):     # all scores equal: the tie rule alone decides - the S lowest slots
+            assert sorted(slot_of[b][int(c)] for c in ob[b].tolist()) == list(range(S))
+
+
+def test_fused_selection_refuses_unsupported_shapes():
+    L = _lib().lib()
+    assert L.skv_select_fused_supported(4, 15560, 256) == 1 and L.skv_select_fused_supported(8, 31128, 512) == 1
+    assert L.skv_select_fused_supported(2, 15560, 256) == 0          # G not in {4, 8}: three-launch path
+    assert L.skv_select_fused_supported(4, 40000, 256) == 0          # more than 32,768 landmarks per head
+    assert L.skv_select_fused_supported(4, 100, 256) == 0
+    assert L.skv_select_state_bytes(8, 4) >= 8 * 4 * 4 and L.skv_select_state_bytes(0, 4) == 0
