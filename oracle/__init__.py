@@ -71,14 +71,15 @@ def group_max_topk(P, landmark_idx, blocks, groups, n, topk):
     return out
 
 
-def fused_candidates(D, fin_m, fin_inv, ctil, topk):
+def fused_candidates(D, fin_m, fin_inv, ctil, topk, level=None):
     """Candidate rule of the device's fused selection (oracle_fused_candidates): D bf16 [blocks, groups, n] logits, fin_m /
-    fin_inv f32 [blocks, groups] softmax finals, ctil f32 [blocks, groups] -> (mask uint8 [blocks, n], counts int32 [blocks])."""
+    fin_inv f32 [blocks, groups] softmax finals, ctil f32 [blocks, groups], level int32 [blocks] (optional witness levels; a
+    level fewer than topk keys reach is ignored) -> (mask uint8 [blocks, n], counts int32 [blocks])."""
     blocks, groups, n = D.shape
     mask = torch.empty(blocks, n, dtype=torch.uint8)
     counts = torch.empty(blocks, dtype=torch.int32)
     lib().oracle_fused_candidates(_p(D), _p(fin_m.contiguous()), _p(fin_inv.contiguous()), _p(ctil.contiguous()), _i(blocks),
-                                  _i(groups), _i(n), _i(topk), _p(mask), _p(counts))
+                                  _i(groups), _i(n), _i(topk), _p(None if level is None else level.contiguous()), _p(mask), _p(counts))
     return mask, counts
 
 

@@ -558,8 +558,12 @@ static float kappa_key_low(int key) {
 }
 static int cmp_u16_desc(const void *a, const void *b) { return (int)*(const uint16_t *)b - (int)*(const uint16_t *)a; }
 
+/* level (per block, nullable): a WITNESS level carried over from the previous step - any key that at least `topk` keys of the
+ * row reach serves in place of k15 (the argument only uses "S slots have kappa >= low(level)"); the device tries the carried
+ * level first and falls back to the exact S-th key when fewer than S keys reach it (or the candidates exceed its limit). */
 ORACLE_API void oracle_fused_candidates(const uint16_t *D, const float *fin_m, const float *fin_inv, const float *ctil,
-                                        int blocks, int groups, int n, int topk, uint8_t *cand, int32_t *counts) {
+                                        int blocks, int groups, int n, int topk, const int32_t *level, uint8_t *cand,
+                                        int32_t *counts) {
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < blocks; ++b) {
         uint16_t *key = (uint16_t *)malloc((size_t)n * 2), *srt = (uint16_t *)malloc((size_t)n * 2);
@@ -574,6 +578,7 @@ ORACLE_API void oracle_fused_candidates(const uint16_t *D, const float *fin_m, c
         }
         qsort(srt, (size_t)n, 2, cmp_u16_desc);
         int k15 = srt[topk - 1];
+        if (level && level[b] >= 8 && level[b] <= k15) k15 = level[b];      /* (level <= S-th key  <=>  at least S keys reach it) */
         double dmax = -1e300, dmin = 1e300;
         for (int g = 0; g < groups; ++g) {
             double c = (double)fin_m[b * groups + g] - log((double)fin_inv[b * groups + g]);

@@ -826,8 +826,8 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
     constexpr int NG = (NW + 15) / 16;
     const int lane = tid & 63, wave = tid >> 6, T = ft.T;
     const bf16_t* const Dt = reinterpret_cast<const bf16_t*>(ft.Dt) + (size_t)b * N * FG;
-    // (1) the tile partials of softmax row g = wave are REQUESTED now (<= 4 per lane: T <= 256) and reduced behind the key
-    //     search, in the contract's order: maximum; sum over tiles lane, lane + 64, .. in that order; the 16-lane tree; rows
+    // (1) the tile partials of softmax row g = wave (<= 4 per lane: T <= 256), reduced in the contract's order: maximum; sum over
+    //     tiles lane, lane + 64, .. in that order; the 16-lane tree; the four rows
     float pmv[4], psv[4];
     float my_ctil = 0.f;
 #pragma unroll
@@ -838,9 +838,7 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
         psv[i] = in ? ft.part_sum[((size_t)b * T + tt) * FG + wave] : 0.0f;
     }
     if (wave < FG) my_ctil = ft.ctil[(size_t)b * FG + wave];
-    // (2) the S-th largest key
-    int thr15, ne15;
-    t2_find_threshold<NW>(w, T2_THREADS * (NW / 4) * 8 - N, S, tid, s_hist, s_w, s_out, thr15, ne15, insert_resident);
+    const int kguess = ft.level[b];                              // witness level carried over from the previous step (0: none)
     if (wave < FG) {
         float m = fmaxf(fmaxf(pmv[0], pmv[1]), fmaxf(pmv[2], pmv[3]));
         m = wave_max_dpp(m);
@@ -861,14 +859,10 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             ft.ctil[(size_t)b * FG + wave] = c;                  // the next step's scan takes its keys against this
         }
     }
-    {   // the histogram is searched again below (either path); all its readers are behind find_threshold's last barrier
-        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
-#pragma unroll
-        for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
-    }
-    __syncthreads();                                             // finals and deltas visible
-    // (3) candidate keys
-    int thr_lo;
+    __syncthreads();                                             // finals visible; the caller's LDS initialisation complete
+    insert_resident();                                           // (hash set of the resident ids: LDS atomics beside the mask work)
+    TOPK_STAMP(12);
+    float spread;
     {
         float dmax = -INFINITY, dmin = INFINITY;
 #pragma unroll
@@ -876,47 +870,98 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             dmax = fmaxf(dmax, s_fin[2 * FG + g]);
             dmin = fminf(dmin, s_fin[2 * FG + g]);
         }
-        const float theta = skv_kappa_key_low(thr15) - (dmax - dmin) - 0.0625f;
-        thr_lo = (theta == theta) ? (int)skv_kappa_key(theta) : 0;            // (NaN: every slot is a candidate)
-        thr_lo = min(thr_lo, thr15);
+        spread = dmax - dmin;
     }
+    // candidates for a witness level `lvl` (at least S keys reach it - to be verified): every key >= key(low(lvl) - spread - 2^-4).
+    // One packed block scan counts the keys >= lvl (low half) and the candidates (high half) and places the candidates'
+    // slots, in slot order, in s_cand.  Returns the two totals packed the same way.
     uint32_t mc[NG];
-    {
+    auto candidates = [&](const int lvl, int* scan_row) __attribute__((always_inline)) -> int {
+        const float theta = skv_kappa_key_low(lvl) - spread - 0.0625f;
+        int thr_lo = (theta == theta) ? (int)skv_kappa_key(theta) : 0;       // (NaN: every slot is a candidate)
+        thr_lo = min(thr_lo, lvl);
         const uint32_t kge = (0x8000u - (uint32_t)thr_lo) * 0x10001u;       // keys are < 0x8000 (15 bits)
+        const uint32_t kgl = (0x8000u - (uint32_t)lvl) * 0x10001u;
+        uint32_t ml[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) mc[g] = 0u;
+        for (int g = 0; g < NG; ++g) {
+            mc[g] = 0u;
+            ml[g] = 0u;
+        }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const uint32_t te = w[i] + kge;
+            const uint32_t te = w[i] + kge, tl = w[i] + kgl;
             mc[i / 16] |= (((te >> 15) & 1u) | ((te >> 31) << 1)) << (2 * (i % 16));
+            ml[i / 16] |= (((tl >> 15) & 1u) | ((tl >> 31) << 1)) << (2 * (i % 16));
         }
-        if (j0 + NW * 2 > N) {                                   // padding (key 0) is never a candidate, whatever thr_lo
+        if (j0 + NW * 2 > N) {                                   // padding (key 0) is never a candidate, whatever the level
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int j = j0 + 2 * i;
-                if (j >= N) mc[i / 16] &= ~(1u << (2 * (i % 16)));
-                if (j + 1 >= N) mc[i / 16] &= ~(2u << (2 * (i % 16)));
+                const uint32_t dead = ((j >= N ? 1u : 0u) | (j + 1 >= N ? 2u : 0u)) << (2 * (i % 16));
+                mc[i / 16] &= ~dead;
+                ml[i / 16] &= ~dead;
             }
         }
-    }
-    int cc = 0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) cc += __builtin_popcount(mc[g]);
-    const int cincl = block_scan_incl1(cc, s_w + 32, tid);
-    if (tid == T2_THREADS - 1) s_out[8] = cincl;
-    if (cincl <= T3_CAND) {                                      // (a thread beyond the limit implies C beyond it)
-        int o = cincl - cc;
+        int cc = 0, cl = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            uint32_t m = mc[g];
-            while (m) {
-                s_cand[o++] = j0 + g * 32 + __builtin_ctz(m);
-                m &= m - 1;
+            cc += __builtin_popcount(mc[g]);
+            cl += __builtin_popcount(ml[g]);
+        }
+        const int pk = cl | (cc << 16);                          // (each total <= 32,768: per thread <= 32 keys)
+        const int pincl = block_scan_incl1(pk, scan_row, tid);
+        if (tid == T2_THREADS - 1) s_out[8] = pincl;
+        const int cincl = (int)((unsigned)pincl >> 16);
+        if (cincl <= T3_CAND) {                                  // (a thread beyond the limit implies a total beyond it)
+            int o = cincl - cc;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                uint32_t m = mc[g];
+                while (m) {
+                    s_cand[o++] = j0 + g * 32 + __builtin_ctz(m);
+                    m &= m - 1;
+                }
             }
         }
+        __syncthreads();
+        return s_out[8];
+    };
+    // (2) the witness level.  Common case: the level the previous step left behind still has at least S keys above it (the
+    // k-th largest score hardly moves from step to step) and few enough candidates - no search at all.  Otherwise (first step,
+    // a jump of the query): the exact S-th largest key, by the histogram search.
+    int level = 0, C = T3_CAND + 1, n_lvl = 0;
+    bool searched = false;
+    if (kguess >= 8 && kguess < 0x8000) {
+        const int tot = candidates(kguess, s_w + 32);
+        n_lvl = tot & 0xffff;
+        C = (int)((unsigned)tot >> 16);
+        level = kguess;
     }
-    __syncthreads();
-    const int C = s_out[8];
+    TOPK_STAMP(13);
+    if (n_lvl < S || C > T3_CAND) {
+        int thr15, ne15;
+        t2_find_threshold<NW>(w, T2_THREADS * (NW / 4) * 8 - N, S, tid, s_hist, s_w, s_out, thr15, ne15, [] {});
+        searched = true;
+        {   // the histogram is searched again below: all its readers are behind find_threshold's last barrier
+            u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+            for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        const int tot = candidates(thr15, s_w + 48);
+        n_lvl = tot & 0xffff;
+        C = (int)((unsigned)tot >> 16);
+        level = thr15;
+    }
+    TOPK_STAMP(14);
+    if (tid == 0) {
+        // the next step's level: just below the S-th key when it was searched; otherwise steered so that S + 16 .. S + 96 keys
+        // stay above it (a level that is too high fails the witness count and costs that step a search, one that is too low
+        // costs candidates)
+        int nl = searched ? level - 1 : (n_lvl > S + 96 ? level + 1 : n_lvl < S + 16 ? level - 1 : level);
+        ft.level[b] = max(nl, 8);
+    }
+    TOPK_STAMP(15);
     if (C <= T3_CAND) {
         // (4) exact scores of the candidates, two per thread in slot order; their chunk ids travel with them
         const int c0 = 2 * tid, c1 = 2 * tid + 1;
@@ -932,8 +977,13 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
         const uint32_t ka = t3_exact_key<FG>(Dt + (size_t)max(ja, 0) * FG, s_fin);
         const uint32_t kb = t3_exact_key<FG>(Dt + (size_t)max(jb, 0) * FG, s_fin);
         const uint32_t w2[1] = {(ja >= 0 ? ka : 0u) | ((jb >= 0 ? kb : 0u) << 16)};
+#ifdef SKV_TOPK_STAMPS
+        if (w2[0] == 0x12345678u) s_out[10] = 1;     // waits for the gathered logits
+        TOPK_STAMP(16);
+#endif
         int thr, need_eq;
         t2_find_threshold<1>(w2, 2 * T2_THREADS - C, S, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+        TOPK_STAMP(17);
         if (thr >= 0x0100) {                                     // a normal bf16 number: the strictness argument holds
             if (eh.dthr_out != nullptr && tid < FG) {            // next step's flag thresholds (early fetch; prediction only)
                 const float kth = __uint_as_float((uint32_t)thr << 16);
@@ -944,7 +994,7 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             const bool va = ja >= 0, vb = jb >= 0;
             const int ga = va && lo > thr, gb = vb && hi > thr, ea = va && lo == thr, eb = vb && hi == thr;
             const int packed = (ga + gb) | ((ea + eb) << 12);    // (<= 1,024 greater, <= 2,048 equal in all)
-            const int pincl = block_scan_incl1(packed, s_w + 48, tid);
+            const int pincl = block_scan_incl1(packed, searched ? s_w + 32 : s_w + 48, tid);
             const int pexcl = pincl - packed;
             int gt_run = pexcl & 0xfff, eq_run = pexcl >> 12;
             if (ga) {
@@ -967,6 +1017,7 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
                 s_cur[gt_run + eq_run] = jb;
                 s_id[gt_run + eq_run] = idb;
             }
+            TOPK_STAMP(18);
             return true;
         }
         u32x4* hz = reinterpret_cast<u32x4*>(s_hist);            // (never for softmax scores of a real head)
@@ -1476,7 +1527,7 @@ int skv_launch_topk_resident(const void* score, int score_stride, const int64_t*
     const int H = 4 * RP;
     FusedTop ft{};
     if (fused) {                     // `score` = the scan launch's 15-bit keys; exact scores are computed from Dt in the kernel
-        if (!score || !fused->Dt || !fused->part_max || !fused->part_sum || !fused->ctil || !skv_fused_select_supported(G, N, S))
+        if (!score || !fused->Dt || !fused->part_max || !fused->part_sum || !fused->ctil || !fused->level || !skv_fused_select_supported(G, N, S))
             return SKV_ERR_UNSUPPORTED;
         ft = *fused;
         const int per_thread = (score_stride / 8 + T2_THREADS - 1) / T2_THREADS;

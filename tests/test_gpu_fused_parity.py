@@ -474,6 +474,9 @@ def test_fused_selection_equals_the_three_launch_path(blocks, G, N, S, kind, inp
             junk = torch.randn(blocks * G, generator=g) * 1e3
             junk[0] = float("inf"); junk[1] = float("-inf")
             state.view(torch.float32)[:blocks * G].copy_(junk)
+            lvl0 = (blocks * G * 4 + 255) // 256 * 256 // 4          # the witness levels sit behind the normalisers (256-B aligned)
+            state.view(torch.int32)[lvl0:lvl0 + blocks].copy_(torch.tensor([-5, 40000, 3, 2 ** 30][:blocks] + [0] * max(0, blocks - 4),
+                                                                           dtype=torch.int32)[:blocks])
         qd = q32.bfloat16().to(DEV)
         ma, sa, na, oa = bufs()
         mb, sb, nb, ob = bufs()

@@ -19,7 +19,7 @@ struct Variant {
 template <int G, int ABL, int WAVES, int PD>
 Variant make(const char* name, const bf16_t* q, bf16_t* D, float* pm, float* ps, int B, int N, int T) {
     return Variant{name, [=](const bf16_t* tab) {
-        hipLaunchKernelGGL((skv_score_tile_kernel<G, ABL, WAVES, PD>), dim3(T, B), dim3(64 * WAVES), 0, 0, q, tab, D, pm, ps, N, T, 0.088f);
+        hipLaunchKernelGGL((skv_score_tile_kernel<G, ABL, WAVES, PD>), dim3(T, B), dim3(64 * WAVES), 0, 0, q, tab, D, pm, ps, N, T, 0.088f, EarlyHooks{}, FusedSel{});
     }, {}};
 }
 

@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
             skv_launch_topk_reorder(dsc2, stride, dlm2, nullptr, dc2, doff2, dcnt2, nullptr, nullptr, B, N, S, 0);
             hipDeviceSynchronize();
         }
-        int rc = skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
+        int rc = skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0, nullptr, nullptr, 0);
         hipDeviceSynchronize();
 #ifdef SKV_TOPK_STAMPS
         unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_topk_stamps), sizeof(st));
@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int it = 0; it < 50; ++it) skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0);
+    for (int it = 0; it < 50; ++it) skv_launch_topk_resident(dsc, stride, nolm ? nullptr : dlm, nullptr, dc, doff, dcnt, nullptr, inplace ? dslot : nullptr, B, N, S, R, R > S ? dage : nullptr, 0, nullptr, nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("back-to-back launches: %.2f us per launch (event time, includes launch boundary)\n", ms * 1e3 / 50);
