@@ -384,17 +384,24 @@ def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=20.0):
             oracle.sparse_attention(q.view(1, kv * G, D), kb, s_["vbuf"], cache.sparse_end + 1, 1.0 / math.sqrt(D))
 
     # thread count: the box may grant this job only a share of its logical CPUs (threads beyond it spin against each
-    # other): a short probe over two layers picks the fastest of a few counts; that count is what is reported
+    # other): a short probe - the ShadowKV path of two layers (every oracle loop of one_step: batch_gemm_softmax, group_max_topk,
+    # reorder, the two gathers, batch_gather_gemm, RoPE push, sparse_attention), best of two repetitions per count - picks the
+    # fastest of a few counts; the probe's table and the count it picked are reported
     one_step(2)
     best = None
+    probe = {}
     for n in (16, 32, 64, 128):
         if n > os.cpu_count():
             break
         oracle.set_num_threads(n)
-        t0 = time.perf_counter()
-        one_step(2)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
+        dt = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            one_step(2)
+            d1 = time.perf_counter() - t0
+            dt = d1 if dt is None else min(dt, d1)
+        probe[n] = round(dt * 1e3, 1)
+        if best is None or dt < best[0] * 0.97:          # (a larger count must win by 3 %: ties go to fewer threads)
             best = (dt, n)
     threads = best[1]
     oracle.set_num_threads(threads)
@@ -428,6 +435,9 @@ def cpu_baseline(model, walk_step, warm=3, timed=10, budget_s=20.0):
                 sample=(f"oracle (C/OpenMP, {threads} threads) ShadowKV path over all {L} layers' state, {warm_done} warm-up + "
                         f"{n_timed} timed decode steps ({path_ms_token:.0f} ms/token = {path_ms_token / L:.1f} ms/layer) + torch-CPU bf16 "
                         f"dense of 1 layer, 1 + 3 repetitions ({dense_ms_layer:.1f} ms/layer) scaled to {L} layers + lm_head"),
+                thread_probe_ms_two_layers=probe,
+                thread_probe="ShadowKV path of 2 layers (all oracle loops of a decode step), best of 2 repetitions per thread count; "
+                             "a larger count must win by 3 %",
                 path_ms_per_token=round(path_ms_token, 1), path_ms_per_layer=round(path_ms_token / L, 2),
                 dense_ms_per_layer=round(dense_ms_layer, 2), timed_steps=n_timed)
 
@@ -740,7 +750,7 @@ def main(argv=None):
                          "replaced - same outputs, fewer chunks over PCIe; in-place layout only)")
     ap.add_argument("--early-fetch", type=int, default=-1,
                     help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
-                         "top-k; -1 = the default for the shape (28 for G <= 4, 64 for G = 8: kv_cache.enable_early_fetch), 0 = off")
+                         "top-k; -1 = the default for the shape (32 for G <= 4, 64 for G = 8 at budget 2048, scaled with the budget: kv_cache.enable_early_fetch), 0 = off")
     ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
     ap.add_argument("--early-fetch-batches", type=int, default=0, choices=[0, 1],
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "

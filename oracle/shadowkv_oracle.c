@@ -528,7 +528,7 @@ ORACLE_API void oracle_rope_new(const uint16_t *x, const uint16_t *cos_sin,
 /* a4 + a5, fused selection (round 4): the candidate rule, restated          */
 /* ------------------------------------------------------------------------- */
 /* The device's fused selection (csrc/skv_select.hip, t3_fused_front) drops the normalise launch: the scan leaves a 15-bit
- * monotone key of kappa_j = min(max_g (D_gj - ctil_g), -2^-12) per slot (ctil = the previous step's log-normalisers), the
+ * monotone fixed-point key (1/256 per code) of kappa_j = min(max_g (D_gj - ctil_g), -2^-12) per slot (ctil = the previous step's log-normalisers), the
  * top-k launch computes this step's finals (m_g, 1 / s_g), takes as CANDIDATES every slot with
  *      key(kappa_j) >= min( key(theta), k15 ),   theta = low(k15) - (max_g delta_g - min_g delta_g) - 2^-4,
  * k15 = the S-th largest key, low(k) = the smallest f32 with key k, delta_g = (m_g + ln s_g) - ctil_g, evaluates the
@@ -543,18 +543,13 @@ ORACLE_API void oracle_rope_new(const uint16_t *x, const uint16_t *cos_sin,
  * inside the candidate set for ANY ctil - zero, exact, perturbed, garbage -, which is all the device needs for identical
  * results.  D [B][G][N] bf16 logits; fin_m / fin_inv [B][G] the finals; ctil [B][G]; cand [B][N] out (1 = candidate);
  * counts [B] out. */
-static uint16_t kappa_key(float x) {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return (uint16_t)(u >> 17);
+static uint16_t kappa_key(float x) {            /* fixed point, 1/256 per code over [-128, 0): csrc/skv_select_front.h */
+    if (!(x > -128.0f)) return 0;
+    float t = (x + 128.0f) * 256.0f;
+    return (uint16_t)(t >= 32767.0f ? 32767 : (int)t);
 }
-static float kappa_key_low(int key) {
-    uint32_t u = (uint32_t)key << 17;
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float x;
-    memcpy(&x, &u, 4);
-    return x;
+static float kappa_key_low(int key) {           /* a lower bound of every value carrying `key` (one code of slack for the rounding) */
+    return key <= 0 ? -INFINITY : (float)(key - 1) * (1.0f / 256.0f) - 128.0f;
 }
 static int cmp_u16_desc(const void *a, const void *b) { return (int)*(const uint16_t *)b - (int)*(const uint16_t *)a; }
 

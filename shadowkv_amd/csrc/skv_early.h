@@ -182,6 +182,10 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
     if (tid <= EF_MAX_E) s_list[tid] = 0;
     __syncthreads();
     skv_early_prep_role<THREADS>(eh, b, tid, smem, part == 0, s_list);
+    // (Measured and dropped, profiles/r04_fused_selection.txt: holding the first host read back until the selection workgroups'
+    // two dependent device-memory round trips are through - device-memory latency stretches chip-wide while host reads are in
+    // flight - by a fixed 3 / 5 / 7 / 9 us from the workgroup's start: 220.4 / 220.5 / 218.0 / 215.8 tokens/s against 220.9 with
+    // no delay at the headline shape, 189.1 against 194.2 at GLM-4's: the link time lost outweighs the stretch.)
     __syncthreads();
     skv_early_pull_role<THREADS>(eh, b, part, tid, s_list, true);
 }

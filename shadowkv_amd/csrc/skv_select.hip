@@ -13,6 +13,7 @@
 //
 // Roofline: the scoring kernel streams the landmark table once (B*N*256 bytes, 31.9 MB per
 // layer at the headline config) and is HBM-bound; everything after it touches <= 1.3 MB.
+#include <stdlib.h>
 #include "skv_common.h"
 #include "skv_select_front.h"
 #include "skv_launch.h"
@@ -955,11 +956,11 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
     }
     TOPK_STAMP(14);
     if (tid == 0) {
-        // the next step's level: just below the S-th key when it was searched; otherwise steered so that S + 16 .. S + 96 keys
-        // stay above it (a level that is too high fails the witness count and costs that step a search, one that is too low
-        // costs candidates)
-        int nl = searched ? level - 1 : (n_lvl > S + 96 ? level + 1 : n_lvl < S + 16 ? level - 1 : level);
-        ft.level[b] = max(nl, 8);
+        // the next step's level (codes of 1/256 in kappa): 0.09 below the S-th key when it was searched; otherwise steered so that
+        // S + S/16 .. S + S/2 keys stay above it - a level that is too high fails the witness count and costs that step a search,
+        // one that is too low only costs candidates (free up to T3_CAND: two per thread either way)
+        int nl = searched ? level - 24 : (n_lvl > S + S / 2 ? level + 6 : n_lvl < S + S / 16 ? level - 12 : level);
+        ft.level[b] = min(max(nl, 8), 32767);
     }
     TOPK_STAMP(15);
     if (C <= T3_CAND) {

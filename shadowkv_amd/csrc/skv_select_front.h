@@ -33,22 +33,23 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     return v;
 }
 
-// 15-bit order-preserving key of an f32 (x <= y  =>  key(x) <= key(y)): the ordered bit pattern - negative: ~bits, otherwise
-// bits | 0x80000000 - shifted down by 17 (sign, exponent, 6 mantissa bits: buckets 2^-6 wide relative).  skv_kappa_key_low(k) is
-// the SMALLEST f32 carrying key k, so "key(x) < k" implies "x < skv_kappa_key_low(k)" and "at least S keys >= k" implies "at least
-// S values >= skv_kappa_key_low(k)" - all the fused selection's exactness argument needs from the quantisation.
+// 15-bit monotone key of kappa (x <= y  =>  key(x) <= key(y)): fixed point, 1/256 per code over [-128, 0) - floor((x + 128) 256),
+// clamped to [0, 32767]; NaN -> 0.  (Round 4, first version: sign / exponent / 6 mantissa bits of the f32 pattern - at kappa ~ -10,
+// GLM-4's 25 K landmarks per head, one code was 0.125 wide = ~250 slots, and the witness level below could only move in steps of
+// 250 slots: it alternated between too few and too many.)  skv_kappa_key_low(k) is the SMALLEST value carrying key k (for k > 0;
+// key 0 also holds everything below -128), so "key(x) < k" implies "x < skv_kappa_key_low(k)" and "at least S keys >= k" implies
+// "at least S values >= skv_kappa_key_low(k)" - all the fused selection's exactness argument needs from the quantisation.
+#define SKV_KAPPA_SCALE 256.0f
+#define SKV_KAPPA_BIAS 128.0f
 __host__ __device__ __forceinline__ uint16_t skv_kappa_key(float x) {
-    uint32_t u;
-    __builtin_memcpy(&u, &x, 4);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return (uint16_t)(u >> 17);
+    if (!(x > -SKV_KAPPA_BIAS)) return 0;                     // (also NaN)
+    const float t = (x + SKV_KAPPA_BIAS) * SKV_KAPPA_SCALE;   // exact scaling; the sum rounds to nearest, monotone
+    return (uint16_t)(t >= 32767.0f ? 32767 : (int)t);
 }
 __host__ __device__ __forceinline__ float skv_kappa_key_low(int key) {
-    uint32_t u = (uint32_t)key << 17;
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float x;
-    __builtin_memcpy(&x, &u, 4);
-    return x;
+    // one code below the key's nominal edge: covers the rounding of (x + 128) in skv_kappa_key (x within 2^-17 of an edge
+    // may land on either side; 2^-8 >> that)
+    return key <= 0 ? -INFINITY : ((float)(key - 1)) * (1.0f / SKV_KAPPA_SCALE) - SKV_KAPPA_BIAS;
 }
 #define T3_CAND 2048                    // candidates the fused selection evaluates exactly on its fast path (two per thread)
 

@@ -1,6 +1,6 @@
 """GPU, BASELINE.json sizes, on the path the headline runs by default (bench.py: in-place layout, attention inside the fetch
 launch, hipGraph, SPECULATIVE EARLY V FETCH ON with the default chunks per head): Llama-3.1-8B shapes at 124,928 tokens
-(config 1: 61 scan tiles per head, E = 28) and GLM-4-9B shapes at 204,800 tokens (config 3: 4 KV heads x 8 query heads, GLM
+(config 1: 61 scan tiles per head, E = 32) and GLM-4-9B shapes at 204,800 tokens (config 3: 4 KV heads x 8 query heads, GLM
 RoPE, 100 scan tiles per head, E = 64), budget 2048, rank 160, 2 layers to keep the run short.  The oracle cannot follow at
 this size in seconds, so the checks are invariants the domain offers:
   * every slot of the sparse region holds exactly the V chunk its position_ids entry names (bytes from the host table:
@@ -20,10 +20,10 @@ from util import rope_pair_bound
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # name: (model config, context tokens, sparse budget, landmarks per head, default early-fetch chunks per head)
-SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928, 2048, 15560, 28), "glm4_200k": ("GLM_4_9B_1M", 204800, 2048, 25544, 64),
+SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928, 2048, 15560, 32), "glm4_200k": ("GLM_4_9B_1M", 204800, 2048, 25544, 64),
           # the reference's 244K regime (test/e2e.py:50-55): budget 4096 -> S = 512, 96 outlier chunks, 122 scan tiles per head,
           # 64 miss tiles + 24 splits = 88 attention records per head
-          "llama31_244k_b4096": ("LLAMA_3_1_8B", 249856, 4096, 31128, 28)}
+          "llama31_244k_b4096": ("LLAMA_3_1_8B", 249856, 4096, 31128, 64)}
 REPLAYS = 6
 _RUNS = {}
 
@@ -58,7 +58,7 @@ def _run(shape, early):
 
 
 @pytest.fixture(scope="module", params=[("llama31_122k", False), ("llama31_122k", True), ("glm4_200k", True), ("llama31_244k_b4096", True)],
-                ids=["llama31_122k-plain", "llama31_122k-early28", "glm4_200k-early64", "llama31_244k_b4096-early"])
+                ids=["llama31_122k-plain", "llama31_122k-early32", "glm4_200k-early64", "llama31_244k_b4096-early64"])
 def decoded(request):
     return _run(*request.param)[0]
 
