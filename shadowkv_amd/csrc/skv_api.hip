@@ -23,6 +23,7 @@ int skv_launch_topk_resident(const void* score, int score_stride, const int64_t*
                              const FusedTop* fused = nullptr, int G = 0);
 bool skv_fused_select_supported(int G, int N, int S);
 int skv_launch_early_init(const EarlyState& es, int B, int G, int n_landmarks, int n_chunks, int E, hipStream_t st);
+int skv_launch_early_map(const EarlyState& es, const int64_t* lm_idx, int B, int N, hipStream_t st);
 int skv_launch_move_rows(const void* host_rows, void* dev, void* temp, const int32_t* offsets, const int32_t* cnts,
                          long long host_len_elems, long long dev_stride_elems, long long dev_off_elems, int B, int S,
                          hipStream_t st);
@@ -303,12 +304,14 @@ size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chun
 
 int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8) {
     if (!out8 || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    // (out8: ten entries since round 4 - 8: the slot -> chunk-id gap table i32 [B][128], 9: its validity flag i32 [B])
     const EarlyState e = skv_carve_early(nullptr, blocks, groups, n_landmarks, n_chunks, early_max);
     const unsigned char* z = nullptr;
     out8[0] = (const unsigned char*)e.dthr - z;      out8[1] = (const unsigned char*)e.finals - z;
     out8[2] = (const unsigned char*)e.flag_cnt - z;  out8[3] = (const unsigned char*)e.flag_slot - z;
     out8[4] = (const unsigned char*)e.early_cnt - z; out8[5] = (const unsigned char*)e.early_ids - z;
     out8[6] = (const unsigned char*)e.early_of - z;  out8[7] = (const unsigned char*)e.staging - z;
+    out8[8] = (const unsigned char*)e.gap_slots - z; out8[9] = (const unsigned char*)e.map_ok - z;
     return SKV_OK;
 }
 
@@ -317,6 +320,13 @@ int skv_early_state_init(void* state, int blocks, int groups, int n_landmarks, i
     if (!state || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     return finish(skv_launch_early_init(skv_carve_early(state, blocks, groups, n_landmarks, n_chunks, early_max), blocks, groups,
                                         n_landmarks, n_chunks, early_max, (hipStream_t)stream));
+}
+
+int skv_early_state_set_landmark_map(void* state, const int64_t* landmark_idx, int blocks, int groups, int n_landmarks,
+                                     int n_chunks, int early_max, skv_stream_t stream) {
+    if (!state || !landmark_idx || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
+    return finish(skv_launch_early_map(skv_carve_early(state, blocks, groups, n_landmarks, n_chunks, early_max), landmark_idx, blocks,
+                                       n_landmarks, (hipStream_t)stream));
 }
 
 int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const int64_t* landmark_idx,
@@ -338,6 +348,8 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
     EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
                   es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
                   (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
+    eh.gap_slots = es.gap_slots;
+    eh.map_ok = es.map_ok;
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;
     rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
@@ -388,6 +400,8 @@ int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t*
         eh = EarlyHooks{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
                         es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
                         (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
+        eh.gap_slots = es.gap_slots;
+        eh.map_ok = es.map_ok;
         hooks = &eh;
     }
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, hooks, &fs);
@@ -414,6 +428,8 @@ int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t*
     EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
                   es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
                   (n_landmarks + 255) / 256, n_landmarks, select_sets, n_chunks, early_max};
+    eh.gap_slots = es.gap_slots;
+    eh.map_ok = es.map_ok;
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;
     rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,

@@ -47,7 +47,7 @@ __device__ __forceinline__ int ef_block_scan_incl(int v, int* s_w, int tid) {
 }
 
 static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
-    return ((size_t)(n_chunks + 31) / 32 + 64) * sizeof(int);
+    return ((size_t)(n_chunks + 31) / 32 + 64 + SKV_EARLY_GAPS) * sizeof(int);   // bitmap | scan scratch | gap table
 }
 
 // One workgroup of THREADS threads for (batch, head) b.  R <= 4 * THREADS resident slots, T * SKV_EARLY_K <= EF_MAX_CAND.
@@ -83,6 +83,10 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
             tcnt[c] = eh.flag_cnt[(size_t)b * T + i / SKV_EARLY_K];
         }
     }
+    // slot -> chunk id without the gather (round 4): the head's gap table, in LDS behind the scan scratch
+    const bool mapped = eh.gap_slots != nullptr && eh.map_ok[b] != 0;      // (uniform)
+    int* const s_gap = s_w + 32;                           // [SKV_EARLY_GAPS]
+    if (mapped && tid < SKV_EARLY_GAPS) s_gap[tid] = eh.gap_slots[(size_t)b * SKV_EARLY_GAPS + tid];
     long long my_res[4];                                   // resident ids of slots tid, tid + THREADS, ... (R <= 4 * THREADS)
 #pragma unroll
     for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
@@ -101,7 +105,17 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
         const bool real = i < total && (i % SKV_EARLY_K) < min(max(tcnt[c], 0), SKV_EARLY_K) && slot[c] >= 0 && slot[c] < N;
         if (real) realm |= 1u << c;
         id[c] = -1;
-        if (c < rounds) id[c] = eh.lm_idx[(size_t)b * N + (real ? slot[c] : 0)];
+        if (c < rounds) {
+            if (mapped) {      // id = slot + #{gaps <= slot}: binary search over the ascending table (7 LDS reads)
+                const int sl = real ? slot[c] : 0;
+                int lo = 0;
+#pragma unroll
+                for (int w = SKV_EARLY_GAPS / 2; w >= 1; w >>= 1) lo += (s_gap[lo + w - 1] <= sl) ? w : 0;
+                id[c] = sl + lo;
+            } else {
+                id[c] = eh.lm_idx[(size_t)b * N + (real ? slot[c] : 0)];
+            }
+        }
     }
     __syncthreads();                                       // the bitmap is complete
     int nkeep = 0;
@@ -175,10 +189,10 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
 // workgroup `part` == 0 also publishes the list for the fetch launch (early_ids, early_of, early_cnt).  The list's "resident"
 // input is the slot -> chunk map the selection workgroup of the same launch rewrites at ITS end (~10 us later): a late pull
 // workgroup that saw some of the new ids would only skip / pull a few other chunks - prediction, never a result.
-// smem: [words(n_chunks) + 64] ints of the list role, then EF_MAX_E + 1 ints of the list.
+// smem: [words(n_chunks) + 64 + SKV_EARLY_GAPS] ints of the list role, then EF_MAX_E + 1 ints of the list.
 template <int THREADS>
 __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* smem) {
-    int* const s_list = smem + (eh.n_chunks + 31) / 32 + 64;
+    int* const s_list = smem + (eh.n_chunks + 31) / 32 + 64 + SKV_EARLY_GAPS;
     if (tid <= EF_MAX_E) s_list[tid] = 0;
     __syncthreads();
     skv_early_prep_role<THREADS>(eh, b, tid, smem, part == 0, s_list);

@@ -75,6 +75,10 @@ struct EarlyHooks {
     void* staging;
     int T, N, R, n_chunks, E;
     int pull_wgs;               // pull workgroups per (batch, head) in the top-k launch (4 for one sequence, 1 for batches)
+    // slot -> chunk id WITHOUT the gather (skv_early_state_set_landmark_map): the landmark ids of a head are the chunk ids in
+    // ascending order minus a few (the outlier chunks), so id(slot) = slot + #{i : gap_slots[i] <= slot}; map_ok[b] == 0: gather
+    const int* gap_slots;       // [B][SKV_EARLY_GAPS] ascending, INT_MAX padded
+    const int* map_ok;          // [B]
 };
 
 // Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.
@@ -86,6 +90,7 @@ struct EarlyHooks {
 //   early_of  [B][chunks] i16 staging index of a chunk pulled early this step, -1 otherwise
 //   staging   [B][E][2 KiB]   the pulled V chunks
 #define SKV_EARLY_K 16
+#define SKV_EARLY_GAPS 128     // chunks that may be missing from a head's ascending landmark-id sequence (outliers: 24 per 1024 budget)
 struct EarlyState {
     float* dthr;
     float* finals;
@@ -95,6 +100,8 @@ struct EarlyState {
     int* early_ids;
     short* early_of;
     void* staging;
+    int* gap_slots;
+    int* map_ok;
     size_t total;
 };
 static inline size_t skv_early_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -111,6 +118,8 @@ static inline EarlyState skv_carve_early(void* base, int B, int G, int n_landmar
     e.early_ids = (int*)(p + off);   off += skv_early_align((size_t)B * E * 4);
     e.early_of = (short*)(p + off);  off += skv_early_align((size_t)B * n_chunks * 2);
     e.staging = p + off;             off += skv_early_align((size_t)B * E * 2048);
+    e.gap_slots = (int*)(p + off);   off += skv_early_align((size_t)B * SKV_EARLY_GAPS * 4);
+    e.map_ok = (int*)(p + off);      off += skv_early_align((size_t)B * 4);
     e.total = off;
     return e;
 }

@@ -768,7 +768,11 @@ class ShadowKVCache_CPU:
         for l in range(self.num_layers):
             check(L.skv_early_state_init(ptr(states[l]), self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, st),
                   "early_state_init")
-        offs = (ctypes.c_longlong * 8)()
+            # slot -> chunk id in closed form (the landmark ids are the chunk ids in ascending order minus the outliers): the
+            # list role then needs no dependent gather; any other landmark_idx is detected on the device and keeps the gather
+            check(L.skv_early_state_set_landmark_map(ptr(states[l]), ptr(self.k_landmark_idx[l]), self.block_num,
+                                                     self.num_key_value_groups, n_lm, n_chunks, E, st), "early_state_set_landmark_map")
+        offs = (ctypes.c_longlong * 10)()
         check(L.skv_early_state_offsets(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs), "early_state_offsets")
         torch.cuda.synchronize(self.device)
         if self._early is not None:

@@ -1,5 +1,6 @@
 """GPU: ShadowKVCache_CPU driven exactly as LLM.layer_compute drives it (models/base.py:315-341) for
 several decode steps, against a CPU mirror advanced by the oracle from the same starting state."""
+import ctypes
 import math
 
 import pytest
@@ -655,3 +656,43 @@ def test_early_fetch_survives_clear_and_a_prompt_of_another_length(first, second
     ca._early["n_lm"] = ca.k_landmark.shape[-2]
     ca.enable_early_fetch(0)
     assert ca._early is None and ca._early_request is None
+
+
+def test_early_fetch_landmark_map_reproduces_the_slot_to_chunk_ids():
+    """skv_early_state_set_landmark_map (round 4): the list role of the early fetch computes a flagged slot's chunk id as
+    slot + #{gaps <= slot} from a table of the chunks the landmark sequence leaves out (the outliers) instead of gathering
+    k_landmark_idx.  The table must reproduce k_landmark_idx exactly for every slot of every head; a landmark_idx that is not
+    "ascending chunk ids minus a few" is flagged on the device and keeps the gather."""
+    from shadowkv_amd import _lib
+    for kv_heads, glm, budget, L in ((8, False, 2048, 16384), (4, True, 4096, 32768)):
+        cache, cs, g = _headline_cache(kv_heads, glm, L=L, seed=7, budget=budget)
+        cache.enable_early_fetch()
+        torch.cuda.synchronize()
+        st, o = cache._early["states"][0], cache._early["offsets"]
+        B, N = cache.block_num, cache.k_landmark.shape[-2]
+        assert len(o) == 10
+        gaps = st[o[8]:o[8] + 4 * B * 128].view(torch.int32).view(B, 128).cpu()
+        ok = st[o[9]:o[9] + 4 * B].view(torch.int32).cpu()
+        assert ok.tolist() == [1] * B
+        idx = cache.k_landmark_idx[0][0].cpu()                                    # [kv, N]
+        slot = torch.arange(N)
+        for h in range(B):
+            assert bool((gaps[h][:-1] <= gaps[h][1:]).all())
+            n_gaps = int((gaps[h] < 2 ** 31 - 1).sum())
+            assert 0 < n_gaps <= budget // 1024 * 24          # the outlier chunks (kv_cache.py:548) below the last landmark
+            ids = slot + (gaps[h].unsqueeze(0) <= slot.unsqueeze(1)).sum(dim=1)
+            assert torch.equal(ids, idx[h]), f"head {h}: the gap table does not reproduce k_landmark_idx"
+    # a landmark_idx that is not ascending: detected, the map is off (the list role gathers as before)
+    L_ = _lib.lib()
+    B, G, N, n_chunks, E = 2, 4, 1000, 1100, 8
+    state = torch.empty(L_.skv_early_state_bytes(B, G, N, n_chunks, E), dtype=torch.uint8, device=DEV)
+    _lib.check(L_.skv_early_state_init(state.data_ptr(), B, G, N, n_chunks, E, 0), "early_state_init")
+    offs = (ctypes.c_longlong * 10)()
+    _lib.check(L_.skv_early_state_offsets(B, G, N, n_chunks, E, offs), "early_state_offsets")
+    good = torch.arange(N, dtype=torch.int64) + (torch.arange(N) >= 500) * 3
+    bad = good.clone(); bad[10], bad[11] = good[11], good[10]
+    lm = torch.stack([good, bad]).to(DEV)
+    _lib.check(L_.skv_early_state_set_landmark_map(state.data_ptr(), lm.data_ptr(), B, G, N, n_chunks, E, 0), "set_landmark_map")
+    torch.cuda.synchronize()
+    assert state[offs[9]:offs[9] + 8].view(torch.int32).cpu().tolist() == [1, 0]
+    assert state[offs[8]:offs[8] + 12].view(torch.int32).cpu().tolist() == [500, 500, 500]
