@@ -22,6 +22,9 @@
 #pragma once
 #include "skv_common.h"
 #include "skv_launch.h"
+#ifndef PULL_STAMP
+#define PULL_STAMP(i)
+#endif
 
 #define EF_MAX_E 128
 #define EF_MAX_CAND 4096                 // flagged slots examined per head and step (more are dropped)
@@ -192,14 +195,23 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
 // smem: [words(n_chunks) + 64 + SKV_EARLY_GAPS] ints of the list role, then EF_MAX_E + 1 ints of the list.
 template <int THREADS>
 __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* smem) {
+#ifdef SKV_TOPK_STAMPS
+    const bool pull_stamp_wg = b == 0 && part == 0;
+#endif
+    PULL_STAMP(24);
     int* const s_list = smem + (eh.n_chunks + 31) / 32 + 64 + SKV_EARLY_GAPS;
     if (tid <= EF_MAX_E) s_list[tid] = 0;
     __syncthreads();
     skv_early_prep_role<THREADS>(eh, b, tid, smem, part == 0, s_list);
+    PULL_STAMP(25);
     // (Measured and dropped, profiles/r04_fused_selection.txt: holding the first host read back until the selection workgroups'
     // two dependent device-memory round trips are through - device-memory latency stretches chip-wide while host reads are in
     // flight - by a fixed 3 / 5 / 7 / 9 us from the workgroup's start: 220.4 / 220.5 / 218.0 / 215.8 tokens/s against 220.9 with
     // no delay at the headline shape, 189.1 against 194.2 at GLM-4's: the link time lost outweighs the stretch.)
     __syncthreads();
     skv_early_pull_role<THREADS>(eh, b, part, tid, s_list, true);
+#ifdef SKV_TOPK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PULL_STAMP(26);
 }

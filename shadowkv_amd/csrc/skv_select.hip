@@ -1580,3 +1580,10 @@ int skv_launch_topk_reorder(const void* score, int score_stride, const int64_t* 
     return skv_launch_topk_resident(score, score_stride, lm_idx, cur_in, cached, offsets, cnts, sel_out, dst_slots, B, N, S, S,
                                     nullptr, st, nullptr, nullptr, 0);
 }
+
+#ifdef SKV_TOPK_STAMPS
+// diagnostic builds only (libshadowkv_hip_stamps.so, tools/topk_stamps.py): the phase stamps of the last top-k launch
+extern "C" __attribute__((visibility("default"))) int skv_debug_topk_stamps(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_topk_stamps), sizeof(g_topk_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -7,13 +7,19 @@
 // Phase stamps for tools/topk_probe.hip (diagnostic build only, -DSKV_TOPK_STAMPS; no stamp executes in the
 // shipped library).  100 MHz wall clock, written by thread 0 of workgroup 0 to a buffer nothing else reads.
 #ifdef SKV_TOPK_STAMPS
-__device__ unsigned long long g_topk_stamps[24];
+__device__ unsigned long long g_topk_stamps[32];
 #define TOPK_STAMP(i)                                                                 \
     do {                                                                              \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64();   \
     } while (0)
+// the FIRST pull workgroup of a launch (early fetch): stamps 24 ..
+#define PULL_STAMP(i)                                                                 \
+    do {                                                                              \
+        if (pull_stamp_wg && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64();     \
+    } while (0)
 #else
 #define TOPK_STAMP(i)
+#define PULL_STAMP(i)
 #endif
 
 // Inclusive integer scans on DPP (no LDS crossbar round trips): within rows of 16 lanes row_shr 1/2/4/8, then
