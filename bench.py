@@ -920,7 +920,7 @@ def main(argv=None):
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": round(roof["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(roof["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; collected by tools/pmc_score.sh in round 3, a separate profiled run - not re-measured inside this run)",
+                               "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; collected by tools/pmc_score.sh in round 4 on the fused-selection form of the launch, a separate profiled run - not re-measured inside this run)",
                                "kernel": roof["kernel"], "launch_form": roof.get("launch"), "us_per_launch": round(roof["us_per_launch"], 3),
                                "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
         out.update(extras)
