@@ -865,6 +865,18 @@ def main(argv=None):
                     extras["value_call_order"]["fraction_of_eager_fused"] = round(extras["value_call_order"]["value"] / r["value"], 3)
             if ref_set and args.layout == "inplace" and args.query_mode == "walk":
                 extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
+            try:     # which branch of the fused selection the heads took in the last step, over all layers
+                fs = [cache.fused_select_stats(l) for l in range(model.num_layers)]
+                if fs[0] is not None:
+                    st = torch.cat(fs)
+                    nh = st.shape[0]
+                    extras["fused_select"] = dict(
+                        heads=nh, level_held=int((st[:, 0] == 0).sum()), level_searched=int(((st[:, 0] & 1) != 0).sum()),
+                        every_slot_evaluated=int(((st[:, 0] & 2) != 0).sum()), mean_candidates=round(float(st[:, 1].float().mean()), 1),
+                        max_candidates=int(st[:, 1].max()), select_sets=cache.select_sets,
+                        note="(layer, KV head) pairs of the last decode step run on this state (same query walk as the timed run); results are identical on every branch")
+            except Exception as e:
+                print(f"[bench] fused-selection statistics failed: {e}", file=sys.stderr)
             if cache._early is not None and args.mode == "graph":
                 # the speculative early V fetch: what it pulled / what the fetch launch then read from staging (last layer of
                 # one more eager step), and the same captured run without it

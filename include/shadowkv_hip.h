@@ -353,10 +353,13 @@ SKV_EXPORT int skv_fetch_kv_attn_inplace(const void* U, const void* SV, const vo
  * counterpart (three CUTLASS kernels + torch.max / topk / gather, /root/reference/models/kv_cache.py:1006-1042).
  * dst_slots null: the reference's slot order (cached_pos_ids reordered in place, miss_ids = offsets); non-null: in-place layout.
  * select_state: skv_select_state_bytes(blocks, groups) bytes of device memory PER LAYER, zeroed once (skv_select_state_init).
+ * Diagnostics of the last launch, int32 [blocks][2] at byte skv_select_state_stats_offset(blocks, groups) of the state: path
+ * (0: the carried level held - no search; bit 0: the level was searched; bit 1: every slot was evaluated) and candidate count.
  * early_state (nullable) + v_host .. margin: the speculative early V fetch as in skv_select_chunks_inplace_early; its list role
  * then runs in the pull workgroups of the top-k launch.  groups in {4, 8}, n_landmarks <= 32,768: skv_select_fused_supported. */
 SKV_EXPORT int skv_select_fused_supported(int groups, int n_landmarks, int select_sets);
 SKV_EXPORT size_t skv_select_state_bytes(int blocks, int groups);
+SKV_EXPORT size_t skv_select_state_stats_offset(int blocks, int groups);
 SKV_EXPORT int skv_select_state_init(void* state, int blocks, int groups, skv_stream_t stream);
 SKV_EXPORT int skv_score_landmarks_fused(const void* q, const void* landmarks, const int64_t* landmark_idx, void* workspace, int blocks,
                               int groups, int n_landmarks, float alpha, void* select_state, void* early_state, int n_chunks,

@@ -45,6 +45,7 @@ _SIGS = {
     "skv_fetch_kv_attn_inplace": (c_int, [c_p] * 12 + [c_int] * 10 + [c_ll] * 4 + [c_int] * 2 + [c_ll, c_int, c_int, c_f, c_p]),
     "skv_select_fused_supported": (c_int, [c_int] * 3),
     "skv_select_state_bytes": (c_sz, [c_int] * 2),
+    "skv_select_state_stats_offset": (c_sz, [c_int] * 2),
     "skv_select_state_init": (c_int, [c_p, c_int, c_int, c_p]),
     "skv_score_landmarks_fused": (c_int, [c_p] * 4 + [c_int] * 3 + [c_f, c_p, c_p, c_int, c_int, c_p]),
     "skv_select_chunks_fused": (c_int, [c_p] * 9 + [c_int] * 5 + [c_p, c_f] + [c_p, c_p, c_p, c_ll, c_int, c_int, c_f, c_p]),

@@ -365,10 +365,14 @@ int skv_select_fused_supported(int groups, int n_landmarks, int select_sets) {
     return skv_fused_select_supported(groups, n_landmarks, select_sets) ? 1 : 0;
 }
 
-// select state of one layer: log-normalisers f32 [blocks][groups], then the witness levels i32 [blocks]
+// select state of one layer: log-normalisers f32 [blocks][groups], then the witness levels i32 [blocks], then the last
+// launch's diagnostics i32 [blocks][2]
 static inline size_t select_state_level_off(int blocks, int groups) { return align256((size_t)blocks * groups * sizeof(float)); }
-size_t skv_select_state_bytes(int blocks, int groups) {
+size_t skv_select_state_stats_offset(int blocks, int groups) {
     return blocks < 1 || groups < 1 ? 0 : select_state_level_off(blocks, groups) + align256((size_t)blocks * sizeof(int));
+}
+size_t skv_select_state_bytes(int blocks, int groups) {
+    return blocks < 1 || groups < 1 ? 0 : skv_select_state_stats_offset(blocks, groups) + align256((size_t)blocks * 2 * sizeof(int));
 }
 
 int skv_select_state_init(void* state, int blocks, int groups, skv_stream_t stream) {
@@ -390,7 +394,8 @@ int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t*
     // the workspace's logit region holds the slot-major logits, its score region the 15-bit keys
     FusedSel fs{(const float*)select_state, (uint16_t*)w.score, w.D, w.score_stride};
     FusedTop ft{w.D, w.pmax, w.psum, (float*)select_state,
-                (int*)((unsigned char*)select_state + select_state_level_off(blocks, groups)), (n_landmarks + 255) / 256};
+                (int*)((unsigned char*)select_state + select_state_level_off(blocks, groups)),
+                (int*)((unsigned char*)select_state + skv_select_state_stats_offset(blocks, groups)), (n_landmarks + 255) / 256};
     EarlyHooks eh{};
     const EarlyHooks* hooks = nullptr;
     if (early_state) {

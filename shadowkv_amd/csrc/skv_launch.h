@@ -46,6 +46,7 @@ struct FusedTop {
     const float* part_sum;
     float* ctil;              // [B][G] in: what the scan's keys were taken against; out: this step's c_g
     int* level;               // [B] in / out: witness level - a key that at least S keys of the row are expected to reach (0: none yet)
+    int* stats;               // [B][2] out: path of this launch (bit 0: the level was searched, bit 1: every slot evaluated), candidates
     int T;
 };
 

@@ -961,6 +961,8 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
         // one that is too low only costs candidates (free up to T3_CAND: two per thread either way)
         int nl = searched ? level - 24 : (n_lvl > S + S / 2 ? level + 6 : n_lvl < S + S / 16 ? level - 12 : level);
         ft.level[b] = min(max(nl, 8), 32767);
+        ft.stats[2 * b] = (searched ? 1 : 0) | (C > T3_CAND ? 2 : 0);     // (diagnostics: skv_select_state_stats_offset)
+        ft.stats[2 * b + 1] = C;
     }
     TOPK_STAMP(15);
     if (C <= T3_CAND) {
@@ -1021,6 +1023,7 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             TOPK_STAMP(18);
             return true;
         }
+        if (tid == 0) ft.stats[2 * b] |= 2;
         u32x4* hz = reinterpret_cast<u32x4*>(s_hist);            // (never for softmax scores of a real head)
 #pragma unroll
         for (int k = 0; k < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++k) hz[tid + k * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};

@@ -781,6 +781,16 @@ class ShadowKVCache_CPU:
                            blocks=self.block_num, offsets=list(offs))
         self._early_request = None
 
+    def fused_select_stats(self, layer_idx):
+        """Per (batch, head) of this layer's last fused selection launch: int32 [blocks, 2] = (path, candidates); path 0: the
+        carried witness level held (no search, only the candidates evaluated), bit 0: the level was searched, bit 1: every
+        slot was evaluated.  None when the fused selection is not in use; diagnostic, synchronises."""
+        G, n = self.num_key_value_groups, self.k_landmark.shape[-2]
+        if not self.fused_select or self._sel_state is None or not lib().skv_select_fused_supported(G, n, self.select_sets):
+            return None
+        off = int(lib().skv_select_state_stats_offset(self.block_num, G))
+        return self._sel_state[layer_idx][off:off + 8 * self.block_num].view(torch.int32).view(self.block_num, 2).cpu()
+
     def early_fetch_counts(self, layer_idx):
         """Chunks pulled early per (batch, head) in the last step of this layer (int32 [blocks]); diagnostic, synchronises."""
         if self._early is None:

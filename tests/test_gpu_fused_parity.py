@@ -465,6 +465,8 @@ def test_fused_selection_equals_the_three_launch_path(blocks, G, N, S, kind, inp
         return (torch.full((blocks, S), -7, dtype=torch.int32, device=DEV), torch.full((blocks, S), -7, dtype=torch.int32, device=DEV),
                 torch.zeros(blocks, dtype=torch.int32, device=DEV), torch.zeros(blocks, S, dtype=torch.int64, device=DEV))
     q32 = torch.randn(blocks, G, 128, generator=g) * 2.0
+    soff = L.lib().skv_select_state_stats_offset(blocks, G)
+    paths = []
     for step in range(7):
         if kind == "jump" or step == 4:
             q32 = torch.randn(blocks, G, 128, generator=g) * (2.0 if step != 4 else 3.5)     # (step 4: a jump in every case)
@@ -501,6 +503,18 @@ def test_fused_selection_equals_the_three_launch_path(blocks, G, N, S, kind, inp
             assert torch.equal(sa, sb), f"{kind} step {step}: destination slots"
         st = state.view(torch.float32)[:blocks * G]
         assert bool(torch.isfinite(st).all()), "the state the launch leaves behind is this step's log-normalisers"
+        stats = state[soff:soff + 8 * blocks].view(torch.int32).view(blocks, 2).cpu()
+        paths.append(stats[:, 0].tolist())
+        for path, ncand in stats.tolist():
+            assert path in (0, 1, 2, 3) and (ncand > 2048) == bool(path & 2) or kind in ("ties", "flat")
+            assert (path & 2) or S <= ncand <= 2048                # the candidates contain the selection
+    # which branch ran (the results above are the same on all of them): no level on the first step -> searched
+    assert all(p & 1 for p in paths[0])
+    if kind == "flat":
+        assert all(p & 2 for step in paths for p in step)          # N candidates > 2,048: every slot evaluated
+    if kind in ("walk", "runs") and N >= 5000:
+        held = sum(p == 0 for step in paths[1:4] + paths[5:] for p in step)
+        assert held > 0, f"the carried level never held on a drifting query: {paths}"
     if kind == "flat":
         slot_of = [{int(c): j for j, c in enumerate(lm_idx[b].tolist())} for b in range(blocks)]
         for b in range(blocks):     # all scores equal: the tie rule alone decides - the S lowest slots

@@ -26,12 +26,12 @@ int main() {
     uint16_t *dlm, *dq, *dD, *dscore; float *dpm, *dps, *dct; int64_t *didx, *dc; int32_t *doff, *dcnt, *dslot;
     hipMalloc(&dlm, lm.size() * 2); hipMalloc(&dq, q.size() * 2); hipMalloc(&dD, (size_t)B * G * N * 2); hipMalloc(&dscore, (size_t)B * stride * 2);
     hipMalloc(&dpm, B * T * G * 4); hipMalloc(&dps, B * T * G * 4); hipMalloc(&dct, B * G * 4); hipMemset(dct, 0, B * G * 4);
-    int* dlvl; hipMalloc(&dlvl, B * 4); hipMemset(dlvl, 0, B * 4);
+    int* dlvl; hipMalloc(&dlvl, B * 12); hipMemset(dlvl, 0, B * 12);
     hipMalloc(&didx, idx.size() * 8); hipMalloc(&dc, cached.size() * 8); hipMalloc(&doff, B * S * 4); hipMalloc(&dcnt, B * 4); hipMalloc(&dslot, B * S * 4);
     hipMemcpy(dlm, lm.data(), lm.size() * 2, hipMemcpyHostToDevice); hipMemcpy(didx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dc, cached.data(), cached.size() * 8, hipMemcpyHostToDevice);
     FusedSel fs{dct, dscore, dD, stride};
-    FusedTop ft{dD, dpm, dps, dct, dlvl, T};
+    FusedTop ft{dD, dpm, dps, dct, dlvl, dlvl + B, T};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto new_q = [&](float step) {
         for (size_t i = 0; i < q.size(); ++i) { qf[i] += step * gauss(); q[i] = f2b(qf[i]); }
