@@ -62,7 +62,7 @@ static inline size_t skv_early_prep_lds_bytes(int n_chunks) {
 // maintain early_of / early_ids / early_cnt): nothing is written to global memory.  s_list (nullable): the kept ids [E] and,
 // in s_list[EF_MAX_E], their number - for a role that goes on in the same workgroup (skv_early_prep_pull_role).
 template <int THREADS>
-__device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem, bool publish = true,
+__device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b, int tid, int* smem, int part = 0, int parts = 1,
                                                     int* s_list = nullptr) {
     constexpr int CPT = EF_MAX_CAND / THREADS;
     const int n_chunks = eh.n_chunks, E = eh.E, T = eh.T, N = eh.N, R = eh.R;
@@ -70,10 +70,12 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     int* const s_bits = smem;                              // [words] resident chunk ids
     int* const s_w = s_bits + words;                       // [<= 16] scan scratch
     const int total = min(T * SKV_EARLY_K, EF_MAX_CAND);
-    // ---- round trip 1.  Last step's early_of entries go back to -1 first (the stores are acknowledged - s_waitcnt below,
-    // behind the gathers every thread waits for anyway - before any thread writes a new entry: the scan's barriers lie between)
-    const int prev_n = min(eh.early_cnt[b], E);
-    const int prev_id = tid < E ? eh.early_ids[(size_t)b * E + tid] : -1;
+    // ---- round trip 1.  The workgroup PUBLISHES the staging slots it owns (e % parts == part: the slots its pull role fills -
+    // one workgroup owns them all when the list is built in the normalise launch): last step's early_of entries of these
+    // slots go back to -1 first (the stores are acknowledged - s_waitcnt below, behind the gathers every thread waits for
+    // anyway - before any thread writes a new entry: the scan's barriers lie between).  early_ids[e] = -1: slot e unused.
+    const bool own_t = tid < E && tid % parts == part;
+    const int prev_id = own_t ? eh.early_ids[(size_t)b * E + tid] : -1;
     const int rounds = (total + THREADS - 1) / THREADS;    // (uniform: 4 at the headline shape, 7 at GLM-4 200K)
     int slot[CPT], tcnt[CPT];
 #pragma unroll
@@ -94,7 +96,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
 #pragma unroll
     for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
-    if (publish && tid < prev_n && prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
+    if (prev_id >= 0 && prev_id < n_chunks) eh.early_of[(size_t)b * n_chunks + prev_id] = (short)-1;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -133,7 +135,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clears above are in L2)
     const int kincl = ef_block_scan_incl<THREADS>(nkeep, s_w, tid);
     if (tid == THREADS - 1) {
-        if (publish) eh.early_cnt[b] = min(kincl, E);
+        if (part == 0) eh.early_cnt[b] = min(kincl, E);
         if (s_list) s_list[EF_MAX_E] = min(kincl, E);
     }
     int pos = kincl - nkeep;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     for (int c = 0; c < CPT; ++c) {
         if ((keepm >> c) & 1u) {
             if (pos < E) {
-                if (publish) {
+                if (pos % parts == part) {
                     eh.early_ids[(size_t)b * E + pos] = (int)id[c];
                     eh.early_of[(size_t)b * n_chunks + id[c]] = (short)pos;
                 }
@@ -149,6 +151,12 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
             }
             ++pos;
         }
+    }
+    if (own_t) {                                           // owned slots behind the end of the list are empty
+        int n_all = 0;                                     // (the scan's wave totals are still in s_w: its last barrier is behind us)
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) n_all += s_w[w];
+        if (tid >= min(n_all, E)) eh.early_ids[(size_t)b * E + tid] = -1;
     }
 }
 
@@ -188,10 +196,17 @@ __device__ __forceinline__ void skv_early_pull_role(const EarlyHooks& eh, int b,
 }
 
 // Fused selection: there is no normalise launch for the list role to ride in, so every pull workgroup of a head builds the
-// head's list itself (same inputs -> same list; ~3 us: two dependent round trips and a block scan) and pulls its share;
-// workgroup `part` == 0 also publishes the list for the fetch launch (early_ids, early_of, early_cnt).  The list's "resident"
-// input is the slot -> chunk map the selection workgroup of the same launch rewrites at ITS end (~10 us later): a late pull
-// workgroup that saw some of the new ids would only skip / pull a few other chunks - prediction, never a result.
+// head's list itself (~3 us: two dependent round trips and a block scan), pulls its share - the staging slots e with
+// e % pull_wgs == part - and publishes EXACTLY those slots for the fetch launch (early_ids[e], early_of[chunk] = e; workgroup 0
+// also the count, a diagnostic).  The list's "resident" input is the slot -> chunk map the selection workgroup of the same
+// launch rewrites at ITS end (~10 us later): should a pull workgroup ever start so late that it sees some of the new ids, its
+// list differs from the other workgroups' - which is why no workgroup publishes another one's slots: early_of[c] = e is only
+// ever written by the workgroup that also writes staging[e], from the same list, so a staged chunk is the chunk its entry
+// names whatever the lists were; differing lists cost duplicate or missing pulls (PCIe bytes), never a result.  (A reset
+// by one workgroup racing a new entry of the same chunk by another - a chunk predicted in two consecutive steps that changes
+// its slot: rare, a predicted chunk is nearly always selected and then resident - leaves -1 or the new slot, in either order
+// (the workgroups sit on different XCDs, their L2s write back at the end of the launch): both are valid, -1 re-reads the
+// chunk from the host.)
 // smem: [words(n_chunks) + 64 + SKV_EARLY_GAPS] ints of the list role, then EF_MAX_E + 1 ints of the list.
 template <int THREADS>
 __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, int b, int part, int tid, int* smem) {
@@ -202,7 +217,7 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
     int* const s_list = smem + (eh.n_chunks + 31) / 32 + 64 + SKV_EARLY_GAPS;
     if (tid <= EF_MAX_E) s_list[tid] = 0;
     __syncthreads();
-    skv_early_prep_role<THREADS>(eh, b, tid, smem, part == 0, s_list);
+    skv_early_prep_role<THREADS>(eh, b, tid, smem, part, eh.pull_wgs, s_list);
     PULL_STAMP(25);
     // (Measured and dropped, profiles/r04_fused_selection.txt: holding the first host read back until the selection workgroups'
     // two dependent device-memory round trips are through - device-memory latency stretches chip-wide while host reads are in

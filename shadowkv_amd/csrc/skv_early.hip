@@ -4,11 +4,12 @@
 #include "skv_common.h"
 #include "skv_launch.h"
 
-__global__ void skv_early_init_kernel(float* dthr, int n_dthr, int* ints, int n_ints, short* early_of, long long n_of, int* map_ok,
-                                      int n_map) {
+__global__ void skv_early_init_kernel(float* dthr, int n_dthr, int* ints, int n_ints, int* early_ids, int n_ids, short* early_of,
+                                      long long n_of, int* map_ok, int n_map) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     for (long long k = i; k < n_dthr; k += stride) dthr[k] = INFINITY;
     for (long long k = i; k < n_ints; k += stride) ints[k] = 0;
+    for (long long k = i; k < n_ids; k += stride) early_ids[k] = -1;  // every staging slot unused
     for (long long k = i; k < n_of; k += stride) early_of[k] = (short)-1;
     for (long long k = i; k < n_map; k += stride) map_ok[k] = 0;      // no slot -> id map yet: the list role gathers
 }
@@ -40,10 +41,10 @@ int skv_launch_early_map(const EarlyState& es, const int64_t* lm_idx, int B, int
 }
 
 int skv_launch_early_init(const EarlyState& es, int B, int G, int n_landmarks, int n_chunks, int E, hipStream_t st) {
-    // flag_cnt .. early_ids are contiguous int regions (see skv_carve_early): zero from flag_cnt to the end of early_ids
-    const long long n_ints = ((unsigned char*)es.early_of - (unsigned char*)es.flag_cnt) / 4;
-    hipLaunchKernelGGL(skv_early_init_kernel, dim3(256), dim3(256), 0, st, es.dthr, B * G, es.flag_cnt, (int)n_ints,
-                       es.early_of, (long long)B * n_chunks, es.map_ok, B);
+    // flag_cnt .. early_cnt are contiguous int regions (see skv_carve_early): zero from flag_cnt to the end of early_cnt
+    const long long n_ints = ((unsigned char*)es.early_ids - (unsigned char*)es.flag_cnt) / 4;
+    hipLaunchKernelGGL(skv_early_init_kernel, dim3(256), dim3(256), 0, st, es.dthr, B * G, es.flag_cnt, (int)n_ints, es.early_ids,
+                       B * E, es.early_of, (long long)B * n_chunks, es.map_ok, B);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
 

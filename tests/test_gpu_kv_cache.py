@@ -516,6 +516,30 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
         big.get_retrieval_position_ids(0, q)
 
 
+def _check_staging_invariant(cache, layer):
+    """What the fetch launch relies on when it reads a chunk from staging instead of the host: early_of[chunk] = e implies
+    early_ids[e] == chunk and staging[e] holds that chunk's bytes - for every entry, whichever workgroup published it (each
+    pull workgroup of the fused selection publishes only the slots it fills, skv_early.h)."""
+    ea = cache._early
+    o, st = ea["offsets"], ea["states"][layer]
+    B, E, nch = cache.block_num, ea["E"], ea["n_chunks"]
+    ids = st[o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
+    of = st[o[6]:o[6] + 2 * B * nch].view(torch.int16).view(B, nch).cpu()
+    staging = st[o[7]:o[7] + B * E * 2048].view(torch.int16).view(B, E, 1024).cpu()
+    vh = cache.v_cache_cpu[layer].view(B, nch, 1024)
+    for b in range(B):
+        named = (of[b] >= 0).nonzero().view(-1)
+        for c in named.tolist():
+            e = int(of[b, c])
+            assert e < E and int(ids[b, e]) == c, (b, c, e, int(ids[b, e]))
+            assert torch.equal(staging[b, e], vh[b, c].view(torch.int16)), (b, c, e)
+        live = ids[b][ids[b] >= 0]
+        assert live.unique().numel() == live.numel()             # one list: no chunk staged twice
+        # (a chunk staged by one workgroup whose LAST step's entry another workgroup resets in the same launch ends with its
+        # new entry or with -1 - the two stores are unordered across XCDs; -1 only means the fetch launch reads it from the host)
+        assert set(named.tolist()) <= set(live.tolist())
+
+
 @pytest.mark.parametrize("kv_heads,glm,budget", [(8, False, 2048), (4, True, 2048), (8, False, 4096), (4, True, 4096), (8, False, 1024)])
 def test_early_fetch_changes_no_bit(kv_heads, glm, budget):
     """Speculative early V fetch (csrc/skv_early.hip): flagged in the scan launch, pulled by a launch on a side stream beside
@@ -555,6 +579,7 @@ def test_early_fetch_changes_no_bit(kv_heads, glm, budget):
             want = vh[h][ids[h].cpu()].view(-1, 128)
             got = ca.v_cache_buffer[0][0][h][ca.sparse_start:ca.sparse_start + ids.shape[1] * 8].cpu()
             assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (step, h)
+        _check_staging_invariant(ca, 0)
         # how many of this step's misses came from staging
         new = (ca.position_ids[0][0] != before)
         used += int(new.sum())
