@@ -150,3 +150,51 @@ def test_early_fetch_changes_no_bit_at_full_size(shape):
         assert all(0 < n <= E * ce.block_num for n in per_layer), (step, per_layer)
     misses = ce.block_num * ce.select_sets * me.num_layers - int(ce._cnts_layers.sum())
     assert misses > 0, "the walk produced no miss in the last step: nothing was fetched"
+
+
+@pytest.mark.parametrize("cfg_name,glm", [("LLAMA_3_1_8B", False), ("GLM_4_9B_1M", True)])
+def test_ninety_steps_agree_across_all_selection_paths(cfg_name, glm):
+    """Soak: 90 captured steps (the generated-row slack allows 96) of one prompt through the four selection paths - fused
+    selection with / without the early fetch, three-launch selection with / without it - on the same query walk: sampled
+    tokens of every step, the final slot -> chunk map, hit counts and both caches bit for bit.  Covers what a 6-step run does
+    not: the witness-level controller of the fused selection over many steps, early-fetch
+    staging slots being reused dozens of times, and the generated rows filling up."""
+    from shadowkv_amd import llama
+    ctx, steps = 32768, 90
+    runs = {}
+    for fused, early in ((True, True), (True, False), (False, True), (False, False)):
+        m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=2048, rank=160,
+                            chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
+        llama.build_synthetic_context(m, ctx, seed=11)
+        m.kv_cache.fused_select = fused
+        if early:
+            m.kv_cache.enable_early_fetch()
+        table = llama.make_walk_table(m, 16, seed=5)
+        dec = llama.GraphDecoder(m, temperature=0.6, walk_table=table)
+        dec.token.copy_(torch.tensor([[7]], device=DEV))
+        warm = dec.capture()
+        toks, paths, pulled = [], [], 0
+        for _ in range(steps - warm):
+            toks.append(int(dec.step()[0, 0]))
+            if fused:
+                paths += [int(p) for l in range(m.num_layers) for p in m.kv_cache.fused_select_stats(l)[:, 0]]
+            if early:
+                pulled += sum(int(m.kv_cache.early_fetch_counts(l).sum()) for l in range(m.num_layers))
+        torch.cuda.synchronize()
+        c = m.kv_cache
+        assert c.fused_select_stats(0) is not None if fused else c.fused_select_stats(0) is None
+        if fused:        # the carried level holds on most steps of a drifting query (the search runs in the eager warm-up steps)
+            assert paths.count(0) > len(paths) // 2, (paths.count(0), len(paths))
+        if early:
+            assert pulled > 0
+        runs[(fused, early)] = (toks, c.position_ids.clone(), c._cnts_layers.clone(), c.k_cache_buffer.view(torch.int16).clone(),
+                                c.v_cache_buffer.view(torch.int16).clone(), c.gen_offset)
+        del dec, m
+        torch.cuda.empty_cache()
+    ref = runs[(False, False)]
+    assert ref[5] == steps and len(set(ref[0])) > 1
+    for key, run in runs.items():
+        assert run[0] == ref[0], (key, "tokens")
+        assert run[5] == ref[5]
+        for a, b, what in zip(run[1:5], ref[1:5], ("position_ids", "cnts", "k cache", "v cache")):
+            assert torch.equal(a, b), (key, what)
