@@ -104,6 +104,7 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
     constexpr int NW = 4 * SEGV, NG = (NW + 15) / 16;
     uint32_t w[NW];
     const int j0 = tid * SEGV * 8;
+    TOPK_STAMP(19);
     {
         const u32x4* gvec = reinterpret_cast<const u32x4*>(row);
         const int nvec = Vp / 8;
@@ -130,8 +131,13 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
 #pragma unroll
         for (int i = 1; i < NW; ++i) m2 = pk_max_u16(m2, w[i]);
         const uint32_t w1[1] = {max(m2 & 0xffffu, m2 >> 16)};               // (high half: padding key 0)
+#ifdef SKV_TOPK_STAMPS
+        if (w1[0] == 0x12345678u) s_out[10] = 1;     // waits for the row
+        TOPK_STAMP(20);
+#endif
         int thr_l, ne_l;
         t2_find_threshold<1>(w1, T2_THREADS, k, tid, s_hist, s_w, s_out, thr_l, ne_l, [] {});
+        TOPK_STAMP(21);
         uint32_t mc[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) mc[g] = 0u;
@@ -162,6 +168,7 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
             }
         }
         __syncthreads();
+        TOPK_STAMP(22);
         const int C = s_out[8];
         if (C <= SMP_CAND) {                                              // (always, unless thousands of logits tie)
             const int c0 = 2 * tid, c1 = 2 * tid + 1;
@@ -170,6 +177,7 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
             const uint32_t w2[1] = {(id0 >= 0 ? k0 : 0u) | ((id1 >= 0 ? k1 : 0u) << 16)};
             int thr, need_eq;
             t2_find_threshold<1>(w2, 2 * T2_THREADS - C, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+            TOPK_STAMP(23);
             const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
             const bool v0 = id0 >= 0, v1 = id1 >= 0;
             const int g0 = v0 && lo > thr, g1 = v1 && hi > thr, e0 = v0 && lo == thr, e1 = v1 && hi == thr;
@@ -180,10 +188,15 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
             const int n_gt = k - need_eq, keep_eq = min(s_out[9], SMP_KEEP - n_gt);
             const int pexcl = pincl - packed;
             int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
-            if (g0) s_cur[gt_run++ + min(eq_run, keep_eq)] = id0;
-            else if (e0) { if (eq_run < keep_eq) s_cur[gt_run + eq_run] = id0; ++eq_run; }
-            if (g1) s_cur[gt_run + min(eq_run, keep_eq)] = id1;
-            else if (e1 && eq_run < keep_eq) s_cur[gt_run + eq_run] = id1;
+            // (the winner's key travels with its id - s_cur[SMP_KEEP + slot] -: no read-back of the logit)
+            auto put = [&](int slot, int idv, int keyv) __attribute__((always_inline)) {
+                s_cur[slot] = idv;
+                s_cur[SMP_KEEP + slot] = keyv;
+            };
+            if (g0) put(gt_run++ + min(eq_run, keep_eq), id0, lo);
+            else if (e0) { if (eq_run < keep_eq) put(gt_run + eq_run, id0, lo); ++eq_run; }
+            if (g1) put(gt_run + min(eq_run, keep_eq), id1, hi);
+            else if (e1 && eq_run < keep_eq) put(gt_run + eq_run, id1, hi);
             n_out = n_gt + keep_eq;
             done = true;
         }
@@ -242,7 +255,10 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
                         if (eq_run < keep_eq) p = gt_run + eq_run;
                         ++eq_run;
                     }
-                    if (p >= 0) s_cur[p] = j0 + g * 32 + e;
+                    if (p >= 0) {
+                        s_cur[p] = j0 + g * 32 + e;
+                        s_cur[SMP_KEEP + p] = -1;                         // key not at hand: read back by the caller
+                    }
                 }
             }
         }
@@ -263,12 +279,12 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
     int* s_out = s_w + 80;                            // [16]
-    int* s_cur = s_out + 16;                          // [64] local token id per winner of the current part (ascending id)
-    int* s_cidx = s_cur + 64;                         // [SMP_CAND] token ids of the prefilter's candidates, ascending
+    int* s_cur = s_out + 16;                          // [2][64] local token id per winner of the current part (ascending id), its key
+    int* s_cidx = s_cur + 2 * SMP_KEEP;               // [SMP_CAND] token ids of the prefilter's candidates, ascending
     float* s_sv = reinterpret_cast<float*>(s_cidx + SMP_CAND);   // [64] sorted: logit / temperature, descending
     int* s_si = reinterpret_cast<int*>(s_sv + 64);    // [64] sorted: token id
-    int* s_ck = s_si + 64;                            // [SMP_PARTS * 64] key of every part's winners (-1: none)
-    int* s_ci = s_ck + SMP_PARTS * SMP_KEEP;          // [SMP_PARTS * 64] their token ids
+    // [SMP_PARTS * 64] (key + 1) << 32 | (0x7fffffff - token id) of every part's winners (16-byte aligned: see the launcher)
+    unsigned long long* s_cc = reinterpret_cast<unsigned long long*>(s_si + 64);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const bf16_t* const row = logits + (size_t)b * row_stride;
     // ---- the winners of every part (a row of <= 131,072 logits is one part)
@@ -277,24 +293,30 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
         const int n = sample_part_topk<SEGV>(row + v0, vp, min(k, vp), tid, s_hist, s_w, s_out, s_cidx, s_cur);
         if (tid < SMP_KEEP) {
             const int id = tid < n ? v0 + s_cur[tid] : 0x7fffffff;
-            // the winner's logit is read back (L2-hot) rather than dug out of the register row by a run-time index
-            s_ck[p * SMP_KEEP + tid] = tid < n ? (int)(bf16x2_to_keys((uint32_t)row[id]) & 0xffffu) : -1;
-            s_ci[p * SMP_KEEP + tid] = id;
+            int wk = tid < n ? s_cur[SMP_KEEP + tid] : 0;
+            if (wk < 0) wk = (int)(bf16x2_to_keys((uint32_t)row[id]) & 0xffffu);   // (the all-slots path: logit read back, L2-hot)
+            // (key + 1, ~id) as ONE 64-bit number: its order is "value descending, token id ascending"; 0 = no winner
+            const unsigned long long kv = tid < n ? (unsigned long long)((uint32_t)wk + 1u) : 0ull;
+            s_cc[p * SMP_KEEP + tid] = (kv << 32) | (unsigned long long)(uint32_t)(0x7fffffff - id);
         }
         if (tid == 0 && p == 0) s_out[12] = 0;
         __syncthreads();
+        TOPK_STAMP(27);
     }
     // ---- merge: rank every winner by (value descending, token id ascending); the k-th of them is the k-th largest logit
     // of the row; everything not below it stays (up to SMP_KEEP), already in sorted order by its rank
     const int nc = parts * SMP_KEEP;
     int key = -1, id = 0x7fffffff, rank = 0x7fffffff;
     if (tid < nc) {
-        key = s_ck[tid];
-        id = s_ci[tid];
-        rank = 0;
-        for (int m = 0; m < nc; ++m) {
-            const int ko = s_ck[m], io = s_ci[m];
-            rank += (ko > key) || (ko == key && io < id);
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long mine = s_cc[tid];
+        key = (int)(mine >> 32) - 1;
+        id = 0x7fffffff - (int)(uint32_t)mine;
+        rank = 0;                                     // winners ahead of this one (the composites of real winners are distinct)
+#pragma unroll 8
+        for (int m = 0; m < nc; m += 2) {             // (one 16-B LDS read per two candidates, all lanes the same address)
+            const u64x2 o = *reinterpret_cast<const u64x2*>(s_cc + m);
+            rank += (o.x > mine) + (o.y > mine);
         }
         if (key >= 0 && rank == k - 1) s_out[11] = key;
     }
@@ -302,6 +324,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     if (tid < nc && key >= s_out[11]) atomicMax(&s_out[12], rank + 1);     // (key >= thr >= 0: a winner)
     __syncthreads();
     const int kk = min(s_out[12], SMP_KEEP);
+    TOPK_STAMP(28);
     if (tid < nc && rank < kk) {
         s_sv[rank] = key_to_float(key) / temperature;
         s_si[rank] = id;
@@ -338,6 +361,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
         hsum = wave_sum_i32(hsum);
         if (lane == 0) hit_accum[0] += hsum;
     }
+    TOPK_STAMP(29);
     if (lane == 0) {
         pos[b] = p0 + 1;
         if (b == 0) {
@@ -356,7 +380,7 @@ static int launch_sample_topk(const void* logits, long long row_stride, int V, i
                               int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
                               long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
                               int64_t* hit_accum, hipStream_t st) {
-    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 3 + SMP_CAND + 2 * SMP_PARTS * SMP_KEEP) * sizeof(int);
+    const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 4 + SMP_CAND + 2 * SMP_PARTS * SMP_KEEP) * sizeof(int);
     static size_t attr_bytes[64] = {};
     if (skv_ensure_max_lds((const void*)skv_sample_topk_kernel<SEGV>, smem, attr_bytes) != SKV_OK) return SKV_ERR_LAUNCH;
     hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
@@ -402,3 +426,10 @@ extern "C" int skv_sample_advance(const float* vals, const int64_t* idx, int bat
                        seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
+
+#ifdef SKV_TOPK_STAMPS
+// diagnostic builds only (libshadowkv_hip_stamps.so, tools/sample_stamps.py): the phase stamps of the last sampler launch
+extern "C" __attribute__((visibility("default"))) int skv_debug_sample_stamps(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_topk_stamps), sizeof(g_topk_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
