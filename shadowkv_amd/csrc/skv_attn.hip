@@ -134,12 +134,15 @@ __global__ __launch_bounds__(256) void skv_attn_merge_kernel(const float* __rest
     {
         const int d = tid & (AT_D - 1), half = tid >> 7;     // records r = half, half + 2, ...
         float a = 0.f, L = 0.f;
+        // (selects, not a branch: the LDS reads of the next records go out while this one is accumulated - as a branch the
+        // loop was one LDS round trip per record)
+#pragma unroll 8
         for (int r = half; r < nrec; r += 2) {
             const float wg = s_wgt[r];
-            if (wg != 0.f) {                                 // dead records may hold anything (also NaN)
-                a = __builtin_fmaf(s_rec[r * AT_REC + d], wg, a);
-                L = __builtin_fmaf(s_rec[r * AT_REC + AT_D + 1], wg, L);
-            }
+            const float ar = s_rec[r * AT_REC + d], lr = s_rec[r * AT_REC + AT_D + 1];
+            const float a2 = __builtin_fmaf(ar, wg, a), l2 = __builtin_fmaf(lr, wg, L);
+            a = wg != 0.f ? a2 : a;                          // dead records may hold anything (also NaN)
+            L = wg != 0.f ? l2 : L;
         }
         s_a[half][d] = a;
         if (d == 0) s_l[half] = L;
