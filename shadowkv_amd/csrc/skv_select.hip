@@ -1127,7 +1127,10 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
         }
         for (int i = tid; i < RP; i += T2_THREADS) s_byslot[i] = -1;
         for (int i = tid; i < SP; i += T2_THREADS) s_rank[i] = 0;
-        if (tid == 0) s_out[6] = 0;
+        if (tid == 0) {
+            s_out[6] = 0;
+            s_out[7] = 0;                                  // "the misses are not in chunk-id order" (set behind barrier (G))
+        }
     }
     auto insert_resident = [&]() __attribute__((always_inline)) {
         if (tid < R && my_cached >= 0) {
@@ -1377,9 +1380,13 @@ __global__ __launch_bounds__(T2_THREADS) void skv_topk2_kernel(
     __syncthreads();
     TOPK_STAMP(8);
     const int cnt = s_out[4], nm = s_out[5];
-    // misses ordered by chunk id: usually sorted already (ascending landmark slot, increasing slot -> id map)
+    // misses ordered by chunk id: usually sorted already (ascending landmark slot, increasing slot -> id map).  The vote is a
+    // wave ballot + one LDS flag + one barrier (__syncthreads_or is a software workgroup reduction: ~1 us at 1,024 threads,
+    // in-kernel stamps)
     const int unsorted_here = (tid > 0 && tid < nm && s_miss[tid - 1] > s_miss[tid]) ? 1 : 0;
-    if (__syncthreads_or(unsorted_here)) {
+    if (__ballot(unsorted_here) != 0ull && (tid & 63) == 0) s_out[7] = 1;
+    __syncthreads();
+    if (s_out[7] != 0) {
         const int P = T2_THREADS / SP;
         const int i = tid / P, part = tid % P;
         if (i < nm) {
