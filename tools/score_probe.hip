@@ -90,5 +90,34 @@ int main() {
         vs.push_back(make<8, 2, 8, 3>("G8  8 waves, depth 3, no statistics tail", q, D, pm, ps, B, N, T));
         bench(vs, tabs, (double)B * N * 256 / 1e6, "GLM-4-9B 200K: B 4, G 8, N 25544, 400 tiles");
     }
+    {   // Yi-9B-200K at 122K / Llama 60K-style shapes: fewer tiles than CUs - one tile's latency chain
+        const int B = 4, G = 8, N = 15560, T = (N + 255) / 256;
+        std::vector<bf16_t*> tabs(48);
+        for (auto& t : tabs) { hipMalloc(&t, (size_t)B * N * 256); hipMemset(t, 0x3c, (size_t)B * N * 256); }
+        bf16_t *q, *D; float *pm, *ps;
+        hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
+        hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
+        std::vector<Variant> vs;
+        vs.push_back(make<8, 0, 8, 8>("G8  8 waves, all up front (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 16, 4>("G8 16 waves, all up front", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 1, 8, 8>("G8  8 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 1, 16, 4>("G8 16 waves, loads only", q, D, pm, ps, B, N, T));
+        bench(vs, tabs, (double)B * N * 256 / 1e6, "Yi-9B 122K: B 4, G 8, N 15560, 244 tiles");
+        for (auto t : tabs) hipFree(t);
+        hipFree(q); hipFree(D); hipFree(pm); hipFree(ps);
+    }
+    {
+        const int B = 8, G = 4, N = 7672, T = (N + 255) / 256;
+        std::vector<bf16_t*> tabs(64);
+        for (auto& t : tabs) { hipMalloc(&t, (size_t)B * N * 256); hipMemset(t, 0x3c, (size_t)B * N * 256); }
+        bf16_t *q, *D; float *pm, *ps;
+        hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
+        hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
+        std::vector<Variant> vs;
+        vs.push_back(make<4, 0, 16, 4>("G4 16 waves, all up front (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 8, 8>("G4  8 waves, all up front", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 1, 16, 4>("G4 16 waves, loads only", q, D, pm, ps, B, N, T));
+        bench(vs, tabs, (double)B * N * 256 / 1e6, "Llama 60K: B 8, G 4, N 7672, 240 tiles");
+    }
     return 0;
 }
