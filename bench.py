@@ -107,6 +107,7 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
         llama.build_synthetic_context(model, ctx, seed=4321 + 100 * rank)
     if not full:
         model.kv_cache.fused_select = bool(getattr(args, "fused_select", 1))
+    model.sampler_ranges = bool(getattr(args, "sampler_ranges", 1))
     if (not full and args.early_fetch and args.v_table == "host" and model.kv_cache.early_fetch_supported()
             and model.kv_cache.select_sets >= 128 and (args.batch == 1 or args.early_fetch_batches)):
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
@@ -766,6 +767,9 @@ def main(argv=None):
     ap.add_argument("--fused-select", type=int, default=1, choices=[0, 1],
                     help="1 (default): selection as scan -> top-k with the logit-domain prefilter (two launches, identical results); "
                          "0: score -> normalise -> top-k")
+    ap.add_argument("--sampler-ranges", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the lm_head launch leaves the largest of every 16 logits, the sampler reads those keys and "
+                         "the ~50 ranges that can hold a top-k logit (same token); 0: the sampler streams the whole logit row")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")

@@ -475,6 +475,22 @@ SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride,
                             long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
                             int64_t* hit_accum, skv_stream_t stream);
 
+/* The lm_head and the sampler without streaming the logit row through one CU (round 4): skv_norm_gemv_rangemax_bf16 is
+ * skv_norm_gemv_bf16 (no fused SiLU) that ALSO leaves, per 16 consecutive outputs, the largest one as an order-preserving
+ * 16-bit key (bf16 x >= 0: x | 0x8000; x < 0: ~x) in range_max[N / 16] (N % 16 == 0); skv_sample_topk_advance_ranges is
+ * skv_sample_topk_advance that finds the ranges able to hold a top-k logit from those keys (the k-th largest range maximum
+ * bounds the k-th largest logit from below) and reads only them - same winners, same draw, bit for bit (a row with more
+ * than 128 qualifying ranges - thousands of tied logits - is streamed as before).  vocab % 16 == 0, vocab <= 262,144,
+ * range_max 16-B aligned, range_stride (keys between rows) % 8 == 0.  The reference has no counterpart (torch.topk over
+ * the f32 logits, /root/reference/models/tensor_op.py:242-297). */
+SKV_EXPORT int skv_norm_gemv_rangemax_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                                void* h_out, const void* bias, void* y, int N, int K, void* range_max, skv_stream_t stream);
+SKV_EXPORT int skv_sample_topk_advance_ranges(const void* logits, long long row_stride, int vocab, const void* range_max,
+                                   long long range_stride, int batch_size, int k, float temperature, float top_p,
+                                   unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen, int64_t* row_idx,
+                                   int32_t* kv_len, int64_t* step_idx, long long base, long long slack, long long table_len,
+                                   const int32_t* hit_cnts, int n_hit_cnts, int64_t* hit_accum, skv_stream_t stream);
+
 /* Page-locked, device-mapped host memory of EXACTLY nbytes for the chunked V table (hipHostMalloc through the HIP runtime
  * this library is linked against - the one the caller's streams and tensors come from).  The reference pins V with
  * torch.zeros(..., pin_memory=True) (/root/reference/models/kv_cache.py:554-563); torch's pinned allocator rounds 8.19 GB

@@ -59,6 +59,7 @@ _SIGS = {
     "skv_sample_advance": (c_int, [c_p] * 2 + [c_int] * 2 + [c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
     "skv_select_from_scores": (c_int, [c_p, c_int] + [c_p] * 6 + [c_int] * 4 + [c_p, c_p]),
     "skv_sample_topk_advance": (c_int, [c_p, c_ll] + [c_int] * 3 + [c_f, c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
+    "skv_sample_topk_advance_ranges": (c_int, [c_p, c_ll, c_int, c_p, c_ll] + [c_int] * 2 + [c_f, c_f, ctypes.c_ulonglong] + [c_p] * 6 + [c_ll] * 3 + [c_p, c_int, c_p, c_p]),
     "skv_score_landmarks": (c_int, [c_p] * 5 + [c_int] * 3 + [c_f, c_p]),
     "skv_score_landmarks_early": (c_int, [c_p] * 6 + [c_int] * 3 + [c_f, c_p, c_int, c_int, c_p]),
     "skv_rebuild_keys": (c_int, [c_p] * 6 + [c_int] * 7 + [c_ll] * 4 + [c_int] * 2 + [c_p] * 3),
@@ -71,6 +72,7 @@ _SIGS = {
     "skv_silu_and_mul": (c_int, [c_p] * 2 + [c_int] * 2 + [c_p]),
     "skv_update_kv_cache": (c_int, [c_p] * 4 + [c_int] * 4 + [c_ll] * 8 + [c_int] * 2 + [c_p]),
     "skv_norm_gemv_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 3 + [c_int] * 3 + [c_p]),
+    "skv_norm_gemv_rangemax_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 3 + [c_int] * 2 + [c_p, c_p]),
     "skv_qkv_gemv_rope_update": (c_int, [c_p] * 4 + [c_f] + [c_p] * 9 + [c_int] * 4 + [c_ll, c_int, c_ll] + [c_int] * 2 + [c_p]),
     "skv_gemv_bf16": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),
     "skv_chunk_stats": (c_int, [c_p, c_ll] + [c_int] * 4 + [c_p] * 3),

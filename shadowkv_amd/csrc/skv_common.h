@@ -28,6 +28,11 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 // bf16 arithmetic, one rounding per operation (CUDA __hmul/__hadd semantics,
 // /root/reference/kernels/rope_new.cu:366-367)
 __device__ __forceinline__ float bfr(float x) { return bf2f(f2bf(x)); }  // round f32 to bf16 grid
+// order-preserving unsigned 16-bit key of a bf16 (x >= 0: x | 0x8000; x < 0: ~x) - the sampler's keys (skv_sample.hip)
+__device__ __forceinline__ uint32_t skv_bf16_order_key(bf16_t b) {
+    const uint32_t w = (uint32_t)b;
+    return (w ^ ((w & 0x8000u) ? 0xffffu : 0x8000u)) & 0xffffu;
+}
 
 // ---- exp contract (oracle spec_exp) ---------------------------------------------------
 __device__ __forceinline__ float spec_exp(float x) {

@@ -35,13 +35,16 @@ struct QkvEpilogue {
     int Hq, Hkv, cache_rows, glm, cs_rows;
 };
 
-template <int R, bool SILU_PAIR, bool NORM, bool QKV>
+// RMAX (lm_head, N % 16 == 0): the workgroup also leaves the LARGEST of its 16 outputs as an order-preserving 16-bit key in
+// range_max[blockIdx.x] - the sampler (skv_sample.hip) then finds the rows that can hold a top-k logit from N / 16 keys
+// instead of streaming all N logits through one CU.
+template <int R, bool SILU_PAIR, bool NORM, bool QKV, bool RMAX = false>
 __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N,
                                                        int K, int I /* SILU_PAIR: rows of one half */,
                                                        const bf16_t* __restrict__ residual,
                                                        const bf16_t* __restrict__ w_norm, bf16_t* __restrict__ h_out,
-                                                       float eps, QkvEpilogue qe) {
+                                                       float eps, QkvEpilogue qe, uint16_t* __restrict__ range_max = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksteps = NORM ? 8 : K / 512;  // 64 lanes x 8 elements per step (NORM: K == 4096, static trip count)
     // rows of this wave
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
         }
         return;
     }
+    __shared__ uint32_t s_kmax[RMAX ? 4 : 1];
     if (lane == 0) {
         if (SILU_PAIR) {
 #pragma unroll
@@ -251,23 +255,38 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
                 }
             }
         } else {
+            uint32_t kmax = 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int n = unit0 + r;
-                if (n < N) y[n] = f2bf(bias ? bfr(tot[r]) + bf2f(bias[n]) : tot[r]);
+                const bf16_t o = f2bf(bias ? bfr(tot[r]) + bf2f(bias[n < N ? n : 0]) : tot[r]);
+                if (n < N) y[n] = o;
+                if (RMAX) kmax = max(kmax, skv_bf16_order_key(o));
             }
+            if constexpr (RMAX) s_kmax[wave] = kmax;
         }
+    }
+    if constexpr (RMAX && !SILU_PAIR && !QKV) {      // (N % 16 == 0: every wave of every workgroup arrives here)
+        __syncthreads();
+        if (tid == 0) range_max[blockIdx.x] = (uint16_t)max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
     }
 }
 
 static int launch_gemv(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                        const void* residual, const void* w_norm, void* h_out, float eps, bool norm, hipStream_t st,
-                       const QkvEpilogue* qkv = nullptr) {
+                       const QkvEpilogue* qkv = nullptr, uint16_t* range_max = nullptr) {
     if (!W || !x || (!y && !qkv) || N < 1) return SKV_ERR_ARG;
     QkvEpilogue qe{};
     if (qkv) qe = *qkv;
     if (K % 8 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
+    if (range_max) {     // the lm_head with the sampler's range keys: norm prologue, whole workgroups of 16 rows
+        if (!norm || qkv || fuse_silu_mul || N % 16) return SKV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((skv_gemv_kernel<4, false, true, false, true>), dim3(N / 16), dim3(256), 0, st, (const bf16_t*)W,
+                           (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, 0, (const bf16_t*)residual,
+                           (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe, range_max);
+        return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+    }
 #define SKV_GEMV(SILU, NORMF, GRID, IARG)                                                                            \
     hipLaunchKernelGGL((skv_gemv_kernel<4, SILU, NORMF, false>), dim3(GRID), dim3(256), 0, st, (const bf16_t*)W,      \
                        (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, IARG, (const bf16_t*)residual,        \
@@ -313,6 +332,14 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
                                   void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                                   skv_stream_t stream) {
     return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, residual, norm_weight, h_out, eps, true, (hipStream_t)stream);
+}
+
+extern "C" int skv_norm_gemv_rangemax_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                                           void* h_out, const void* bias, void* y, int N, int K, void* range_max,
+                                           skv_stream_t stream) {
+    if (!range_max) return SKV_ERR_ARG;
+    return launch_gemv(W, x, bias, y, N, K, 0, residual, norm_weight, h_out, eps, true, (hipStream_t)stream, nullptr,
+                       (uint16_t*)range_max);
 }
 
 extern "C" int skv_qkv_gemv_rope_update(const void* Wqkv, const void* x, const void* residual, const void* norm_weight,

@@ -92,6 +92,116 @@ __device__ __forceinline__ float key_to_float(int key) {
 #define SMP_KEEP 64                  // winners a row (or a part of it) can hand on: k plus the logits tied with the k-th
 #define SMP_PARTS 4                  // a row is searched in parts of <= 131,072 logits (16 vectors per thread)
 
+// Exact top-k among C <= SMP_CAND candidate logits (two per thread, candidate c = local token id id_of(c), ascending): the
+// k-th largest value by the histogram search, then every candidate above it and the ones equal to it (ascending id, up to
+// SMP_KEEP winners in all) into s_cur[0 .. n) with their keys in s_cur[SMP_KEEP ..]; returns n.  The histogram must be zero;
+// the caller ends with a barrier.
+template <typename F>
+__device__ __forceinline__ int sample_candidates_topk(const bf16_t* __restrict__ row, const int C, const int k, const int tid,
+                                                      int* s_hist, int* s_w, int* s_out, int* s_cur, F id_of) {
+        const int c0 = 2 * tid, c1 = 2 * tid + 1;
+        const int id0 = c0 < C ? id_of(c0) : -1, id1 = c1 < C ? id_of(c1) : -1;
+        const uint32_t k0 = bf16x2_to_keys((uint32_t)row[max(id0, 0)]) & 0xffffu, k1 = bf16x2_to_keys((uint32_t)row[max(id1, 0)]) & 0xffffu;
+        const uint32_t w2[1] = {(id0 >= 0 ? k0 : 0u) | ((id1 >= 0 ? k1 : 0u) << 16)};
+        int thr, need_eq;
+        t2_find_threshold<1>(w2, 2 * T2_THREADS - C, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+        TOPK_STAMP(23);
+        const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
+        const bool v0 = id0 >= 0, v1 = id1 >= 0;
+        const int g0 = v0 && lo > thr, g1 = v1 && hi > thr, e0 = v0 && lo == thr, e1 = v1 && hi == thr;
+        const int packed = (g0 + g1) | ((e0 + e1) << 10);             // (<= 64 greater, <= 2,048 equal in all)
+        const int pincl = block_scan_incl1(packed, s_w + 48, tid);
+        if (tid == T2_THREADS - 1) s_out[9] = pincl >> 10;            // logits equal to the k-th value
+        __syncthreads();
+        const int n_gt = k - need_eq, keep_eq = min(s_out[9], SMP_KEEP - n_gt);
+        const int pexcl = pincl - packed;
+        int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
+        // (the winner's key travels with its id - s_cur[SMP_KEEP + slot] -: no read-back of the logit)
+        auto put = [&](int slot, int idv, int keyv) __attribute__((always_inline)) {
+            s_cur[slot] = idv;
+            s_cur[SMP_KEEP + slot] = keyv;
+        };
+        if (g0) put(gt_run++ + min(eq_run, keep_eq), id0, lo);
+        else if (e0) { if (eq_run < keep_eq) put(gt_run + eq_run, id0, lo); ++eq_run; }
+        if (g1) put(gt_run + min(eq_run, keep_eq), id1, hi);
+        else if (e1 && eq_run < keep_eq) put(gt_run + eq_run, id1, hi);
+        return n_gt + keep_eq;
+}
+
+// The same through RANGE MAXIMA (round 4): range_max[r] = key of the largest of logits 16 r .. 16 r + 15, left by the lm_head
+// launch (skv_gemv.hip, RMAX).  The k-th largest range maximum L is a lower bound of the k-th largest logit (k ranges hold a
+// logit >= L), so every winner lies in a range whose maximum reaches L: about k ranges = 16 k candidates.  The workgroup
+// reads n_ranges keys (16 KB at 128 K logits) and ~1,000 logits instead of streaming the whole row through ONE CU (256 KB
+// at the per-CU rate: 10.5 of the launch's 23 us, profiles/r04_sample_stamps.txt).  Returns the number of winners in
+// s_cur (as sample_part_topk, local id = token id), or -1 when more than SMP_CAND / 16 ranges qualify (thousands of tied
+// logits: the caller streams the row).  n_ranges <= 16,384, n_ranges >= k.  Ends with a barrier unless it returns -1.
+#define SMP_RANGE 16
+__device__ __forceinline__ int sample_ranges_topk(const bf16_t* __restrict__ row, const uint16_t* __restrict__ rmax, const int n_ranges,
+                                                  const int k, const int tid, int* s_hist, int* s_w, int* s_out, int* s_cidx,
+                                                  int* s_cur) {
+    constexpr int SEGR = 2, NW = 4 * SEGR;                              // 16 range keys per thread
+    uint32_t w[NW];
+    const int r0 = tid * NW * 2;
+    TOPK_STAMP(19);
+    {
+        const u32x4* gvec = reinterpret_cast<const u32x4*>(rmax);
+        const int nvec = n_ranges / 8;                                  // (whole vectors; the tail below)
+#pragma unroll
+        for (int q = 0; q < SEGR; ++q) {
+            const int vi = tid * SEGR + q;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (vi < nvec) v = gvec[vi];
+            else if (vi == nvec && (n_ranges & 7)) {                    // n_ranges % 8 keys of the last vector, one by one
+                for (int e = 0; e < (n_ranges & 7); ++e) v[e >> 1] |= (uint32_t)rmax[8 * nvec + e] << (16 * (e & 1));
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) w[4 * q + x] = v[x];            // (already keys; padding: key 0)
+        }
+    }
+    {
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+        for (int q = 0; q < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++q) hz[tid + q * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+    }
+#ifdef SKV_TOPK_STAMPS
+    if (w[0] == 0x12345678u) s_out[10] = 1;
+    TOPK_STAMP(20);
+#endif
+    int thr_l, ne_l;
+    t2_find_threshold<NW>(w, T2_THREADS * NW * 2 - n_ranges, k, tid, s_hist, s_w, s_out, thr_l, ne_l, [] {});
+    TOPK_STAMP(21);
+    uint32_t mc = 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int lo = (int)(w[i] & 0xffffu), hi = (int)(w[i] >> 16);
+        mc |= ((uint32_t)(lo >= thr_l && r0 + 2 * i < n_ranges) | ((uint32_t)(hi >= thr_l && r0 + 2 * i + 1 < n_ranges) << 1)) << (2 * i);
+    }
+    const int cc = __builtin_popcount(mc);
+    const int cincl = block_scan_incl1(cc, s_w + 32, tid);
+    if (tid == T2_THREADS - 1) s_out[8] = cincl;
+    {   // the histogram is searched again below
+        u32x4* hz = reinterpret_cast<u32x4*>(s_hist);
+#pragma unroll
+        for (int q = 0; q < T2_BINS * T2_COPIES / 4 / T2_THREADS; ++q) hz[tid + q * T2_THREADS] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if (cincl <= SMP_CAND / SMP_RANGE) {
+        int o = cincl - cc;
+        uint32_t m = mc;
+        while (m) {
+            s_cidx[o++] = r0 + __builtin_ctz(m);                        // qualifying ranges, ascending
+            m &= m - 1;
+        }
+    }
+    __syncthreads();
+    TOPK_STAMP(22);
+    const int CR = s_out[8];
+    if (CR > SMP_CAND / SMP_RANGE) return -1;
+    const int n = sample_candidates_topk(row, CR * SMP_RANGE, k, tid, s_hist, s_w, s_out, s_cur,
+                                         [&](int c) { return s_cidx[c / SMP_RANGE] * SMP_RANGE + (c % SMP_RANGE); });
+    __syncthreads();                                                    // the winners in s_cur are visible
+    return n;
+}
+
 // Exact top-k of ONE part of a logit row (Vp <= 131,072 logits starting at `row`), all 1,024 threads: the part lives in
 // registers, the k-th largest of the 1,024 per-thread maxima bounds the candidates, the exact search (4,096-bin histogram
 // counted down from the maximum, skv_select_front.h) runs on those few dozen.  Leaves in s_cur[0 .. n) the LOCAL ids,
@@ -171,33 +281,7 @@ __device__ __forceinline__ int sample_part_topk(const bf16_t* __restrict__ row, 
         TOPK_STAMP(22);
         const int C = s_out[8];
         if (C <= SMP_CAND) {                                              // (always, unless thousands of logits tie)
-            const int c0 = 2 * tid, c1 = 2 * tid + 1;
-            const int id0 = c0 < C ? s_cidx[c0] : -1, id1 = c1 < C ? s_cidx[c1] : -1;
-            const uint32_t k0 = bf16x2_to_keys((uint32_t)row[max(id0, 0)]) & 0xffffu, k1 = bf16x2_to_keys((uint32_t)row[max(id1, 0)]) & 0xffffu;
-            const uint32_t w2[1] = {(id0 >= 0 ? k0 : 0u) | ((id1 >= 0 ? k1 : 0u) << 16)};
-            int thr, need_eq;
-            t2_find_threshold<1>(w2, 2 * T2_THREADS - C, k, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
-            TOPK_STAMP(23);
-            const int lo = (int)(w2[0] & 0xffffu), hi = (int)(w2[0] >> 16);
-            const bool v0 = id0 >= 0, v1 = id1 >= 0;
-            const int g0 = v0 && lo > thr, g1 = v1 && hi > thr, e0 = v0 && lo == thr, e1 = v1 && hi == thr;
-            const int packed = (g0 + g1) | ((e0 + e1) << 10);             // (<= 64 greater, <= 2,048 equal in all)
-            const int pincl = block_scan_incl1(packed, s_w + 48, tid);
-            if (tid == T2_THREADS - 1) s_out[9] = pincl >> 10;            // logits equal to the k-th value
-            __syncthreads();
-            const int n_gt = k - need_eq, keep_eq = min(s_out[9], SMP_KEEP - n_gt);
-            const int pexcl = pincl - packed;
-            int gt_run = pexcl & 1023, eq_run = pexcl >> 10;
-            // (the winner's key travels with its id - s_cur[SMP_KEEP + slot] -: no read-back of the logit)
-            auto put = [&](int slot, int idv, int keyv) __attribute__((always_inline)) {
-                s_cur[slot] = idv;
-                s_cur[SMP_KEEP + slot] = keyv;
-            };
-            if (g0) put(gt_run++ + min(eq_run, keep_eq), id0, lo);
-            else if (e0) { if (eq_run < keep_eq) put(gt_run + eq_run, id0, lo); ++eq_run; }
-            if (g1) put(gt_run + min(eq_run, keep_eq), id1, hi);
-            else if (e1 && eq_run < keep_eq) put(gt_run + eq_run, id1, hi);
-            n_out = n_gt + keep_eq;
+            n_out = sample_candidates_topk(row, C, k, tid, s_hist, s_w, s_out, s_cur, [&](int c) { return s_cidx[c]; });
             done = true;
         }
     }
@@ -274,7 +358,8 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     float top_p, unsigned long long seed, int64_t* __restrict__ token, int64_t* __restrict__ pos, int64_t* __restrict__ gen,
     int64_t* __restrict__ row_idx, int32_t* __restrict__ kv_len, int64_t* __restrict__ step_idx, long long base,
     long long slack, long long table_len, const int32_t* __restrict__ hit_cnts, int n_hit_cnts,
-    int64_t* __restrict__ hit_accum) {
+    int64_t* __restrict__ hit_accum, const uint16_t* __restrict__ range_max /* nullable: [bs][range_stride] */,
+    long long range_stride) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     int* s_hist = smem;                               // [T2_BINS][T2_COPIES]
     int* s_w = s_hist + T2_BINS * T2_COPIES;          // [80]
@@ -287,6 +372,22 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     unsigned long long* s_cc = reinterpret_cast<unsigned long long*>(s_si + 64);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const bf16_t* const row = logits + (size_t)b * row_stride;
+    // ---- through the lm_head's range maxima when it left them: the row is not streamed at all
+    if (range_max != nullptr) {
+        const int n = sample_ranges_topk(row, range_max + (size_t)b * range_stride, V / SMP_RANGE, k, tid, s_hist, s_w, s_out,
+                                         s_cidx, s_cur);
+        if (n >= 0) {                                        // (uniform)
+            if (tid < SMP_KEEP) {
+                const int id = tid < n ? s_cur[tid] : 0x7fffffff;
+                const unsigned long long kv = tid < n ? (unsigned long long)((uint32_t)s_cur[SMP_KEEP + tid] + 1u) : 0ull;
+                s_cc[tid] = (kv << 32) | (unsigned long long)(uint32_t)(0x7fffffff - id);
+            }
+            if (tid == 0) s_out[12] = 0;
+            __syncthreads();
+            TOPK_STAMP(27);
+            parts = 0;                                       // no part is searched; the merge ranks the SMP_KEEP entries above
+        }
+    }
     // ---- the winners of every part (a row of <= 131,072 logits is one part)
     for (int p = 0; p < parts; ++p) {
         const int v0 = p * part_len, vp = min(part_len, V - v0);
@@ -305,7 +406,7 @@ __global__ __launch_bounds__(T2_THREADS) void skv_sample_topk_kernel(
     }
     // ---- merge: rank every winner by (value descending, token id ascending); the k-th of them is the k-th largest logit
     // of the row; everything not below it stays (up to SMP_KEEP), already in sorted order by its rank
-    const int nc = parts * SMP_KEEP;
+    const int nc = max(parts, 1) * SMP_KEEP;
     int key = -1, id = 0x7fffffff, rank = 0x7fffffff;
     if (tid < nc) {
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -379,21 +480,21 @@ static int launch_sample_topk(const void* logits, long long row_stride, int V, i
                               float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
                               int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
                               long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
-                              int64_t* hit_accum, hipStream_t st) {
+                              int64_t* hit_accum, const uint16_t* range_max, long long range_stride, hipStream_t st) {
     const size_t smem = (size_t)(T2_BINS * T2_COPIES + 80 + 16 + 64 * 4 + SMP_CAND + 2 * SMP_PARTS * SMP_KEEP) * sizeof(int);
     static size_t attr_bytes[64] = {};
     if (skv_ensure_max_lds((const void*)skv_sample_topk_kernel<SEGV>, smem, attr_bytes) != SKV_OK) return SKV_ERR_LAUNCH;
     hipLaunchKernelGGL(skv_sample_topk_kernel<SEGV>, dim3(bs), dim3(T2_THREADS), smem, st, (const bf16_t*)logits, row_stride,
                        V, parts, part_len, k, temperature, top_p, seed, token, pos, gen, row_idx, kv_len, step_idx, base, slack,
-                       table_len, hit_cnts, n_hit_cnts, hit_accum);
+                       table_len, hit_cnts, n_hit_cnts, hit_accum, range_max, range_stride);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
 
-extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
-                                       float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
-                                       int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
-                                       long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
-                                       int64_t* hit_accum, skv_stream_t stream) {
+static int sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
+                              float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
+                              int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                              long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                              int64_t* hit_accum, const uint16_t* range_max, long long range_stride, skv_stream_t stream) {
     if (!logits || !token || !pos || !gen || !row_idx || !kv_len || batch_size < 1 || !(temperature > 0.f)) return SKV_ERR_ARG;
     if (k < 1 || k > 64 || vocab < k || slack < 1 || (step_idx && table_len < 1)) return SKV_ERR_UNSUPPORTED;
     constexpr int PART_MAX = T2_THREADS * 16 * 8;          // logits one pass holds in registers
@@ -404,15 +505,41 @@ extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride,
     const int part_len = (((vocab + parts - 1) / parts) + 7) & ~7;
     if (vocab - (parts - 1) * part_len < k) return SKV_ERR_UNSUPPORTED;   // (never for real vocabularies)
     const int per_thread = (part_len / 8 + T2_THREADS - 1) / T2_THREADS;
+    if (range_max) {    // 16-logit ranges, 16 keys per thread, 16-B vectors of keys
+        if ((vocab % SMP_RANGE) || vocab / SMP_RANGE > T2_THREADS * 16 || vocab / SMP_RANGE < k || (((size_t)range_max) & 15) ||
+            (range_stride % 8) || range_stride < vocab / SMP_RANGE)
+            return SKV_ERR_UNSUPPORTED;
+    }
 #define SKV_ST(SV) launch_sample_topk<SV>(logits, row_stride, vocab, parts, part_len, batch_size, k, temperature, top_p, seed, \
                                           token, pos, gen, row_idx, kv_len, step_idx, base, slack, table_len, hit_cnts,         \
-                                          n_hit_cnts, hit_accum, st)
+                                          n_hit_cnts, hit_accum, range_max, range_stride, st)
     if (per_thread <= 1) return SKV_ST(1);
     if (per_thread <= 2) return SKV_ST(2);
     if (per_thread <= 4) return SKV_ST(4);
     if (per_thread <= 8) return SKV_ST(8);
     return SKV_ST(16);
 #undef SKV_ST
+}
+
+extern "C" int skv_sample_topk_advance(const void* logits, long long row_stride, int vocab, int batch_size, int k,
+                                       float temperature, float top_p, unsigned long long seed, int64_t* token, int64_t* pos,
+                                       int64_t* gen, int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                                       long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                                       int64_t* hit_accum, skv_stream_t stream) {
+    return sample_topk_advance(logits, row_stride, vocab, batch_size, k, temperature, top_p, seed, token, pos, gen, row_idx, kv_len,
+                               step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum, nullptr, 0, stream);
+}
+
+extern "C" int skv_sample_topk_advance_ranges(const void* logits, long long row_stride, int vocab, const void* range_max,
+                                              long long range_stride, int batch_size, int k, float temperature, float top_p,
+                                              unsigned long long seed, int64_t* token, int64_t* pos, int64_t* gen,
+                                              int64_t* row_idx, int32_t* kv_len, int64_t* step_idx, long long base,
+                                              long long slack, long long table_len, const int32_t* hit_cnts, int n_hit_cnts,
+                                              int64_t* hit_accum, skv_stream_t stream) {
+    if (!range_max) return SKV_ERR_ARG;
+    return sample_topk_advance(logits, row_stride, vocab, batch_size, k, temperature, top_p, seed, token, pos, gen, row_idx, kv_len,
+                               step_idx, base, slack, table_len, hit_cnts, n_hit_cnts, hit_accum, (const uint16_t*)range_max,
+                               range_stride, stream);
 }
 
 extern "C" int skv_sample_advance(const float* vals, const int64_t* idx, int batch_size, int k, float top_p,

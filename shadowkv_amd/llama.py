@@ -133,6 +133,11 @@ class DecoderLM:
                                               rank=rank, v_offload=v_offload, resident_sets=resident_sets)
         self.query_hook = None   # optional: q -> q used for selection/attention (bench: synthetic query walk)
         self._sampler_state = {}
+        # lm_head -> sampler through range maxima (round 4): the lm_head launch of forward_fused leaves the largest of every 16
+        # logits as a 16-bit key, the native sampler reads those instead of streaming the row through one CU (same token)
+        self.sampler_ranges = True
+        self._range_max = None          # int16 [1, vocab / 16 rounded up to 8]
+        self._last_range_max = None     # the keys of the logits forward_fused returned last (None: not produced)
 
     def weight_bytes(self):
         n = self.lm_head.numel()   # one embedding row is read per token: not counted
@@ -338,7 +343,15 @@ class DecoderLM:
                                                          layer.post_attention_layernorm_variance_epsilon,
                                                          layer.gate_up_proj, fuse_silu_mul=True)
             x = tensor_op.linear_decode(act, layer.down_proj)
-        _, logits = tensor_op.norm_linear_decode(x, residual, self.norm_weight, self.norm_variance_epsilon, self.lm_head)
+        V = self.lm_head.shape[0]
+        rm = None
+        if self.sampler_ranges and not as_float and x.is_cuda and tensor_op.range_max_supported(x.numel(), x.shape[-1], V):
+            if self._range_max is None:
+                self._range_max = torch.zeros(1, (V // 16 + 7) // 8 * 8, dtype=torch.int16, device=x.device)
+            rm = self._range_max
+        self._last_range_max = rm
+        _, logits = tensor_op.norm_linear_decode(x, residual, self.norm_weight, self.norm_variance_epsilon, self.lm_head,
+                                                 range_max=rm)
         return logits.float() if as_float else logits        # (the native sampler reads the bf16 row as it is)
 
     def get_ctx(self, input_ids):
@@ -361,6 +374,7 @@ class DecoderLM:
     def decode_step(self, next_token, temperature=0.6, top_p=0.9, top_k=50, q_table=None, fused=True):
         """One iteration of the reference's timed loop (base.py:628-635).  fused=False runs the reference's
         exact call order through the reference-shaped methods (inference / layer_compute)."""
+        self._last_range_max = None
         if not fused:
             logits = self.inference(input_ids=next_token, position_ids=self.get_ctx(next_token), as_float=False)
         else:
@@ -379,7 +393,8 @@ class DecoderLM:
             logits = self.forward_fused(next_token, pos, row_idx, kv_len=row + 1, q_table=q_table, as_float=False)
             c.note_kv_appended(1)
         return tensor_op.sample_token(logits[:, -1, :], temperature=temperature, top_p=top_p, top_k=top_k,
-                                      state=self._sampler_state)   # (draw counters of THIS model)
+                                      state=self._sampler_state,   # (draw counters of THIS model)
+                                      range_max=self._last_range_max)
 
 
 class Llama(DecoderLM):
@@ -582,12 +597,15 @@ class GraphDecoder:
                 and V <= self.NATIVE_SAMPLER_MAX_VOCAB and last.stride(-1) == 1 and last.stride(0) % 8 == 0
                 and last.data_ptr() % 16 == 0):
             # ONE native launch from the bf16 logits: exact top-k, temperature, top-p, draw, every counter of the step
-            check(lib().skv_sample_topk_advance(ptr(last), last.stride(0), V, last.shape[0], k, float(self.temperature),
-                                                float(self.top_p), self.seed, ptr(self.token), ptr(self.pos), ptr(self.gen),
-                                                ptr(self.row_idx), ptr(self.kv_len),
-                                                ptr(self.step_idx) if self.walk_table is not None else 0, self.base,
-                                                self.slack, tlen, *self._hit_args(), current_stream_handle()),
-                  "sample_topk_advance")
+            tail = (last.shape[0], k, float(self.temperature), float(self.top_p), self.seed, ptr(self.token), ptr(self.pos),
+                    ptr(self.gen), ptr(self.row_idx), ptr(self.kv_len), ptr(self.step_idx) if self.walk_table is not None else 0,
+                    self.base, self.slack, tlen, *self._hit_args(), current_stream_handle())
+            rm = m._last_range_max
+            if rm is not None and V // 16 >= k:      # the lm_head left the range maxima of THIS row: the row is not streamed
+                check(lib().skv_sample_topk_advance_ranges(ptr(last), last.stride(0), V, ptr(rm), rm.stride(0), *tail),
+                      "sample_topk_advance_ranges")
+            else:
+                check(lib().skv_sample_topk_advance(ptr(last), last.stride(0), V, *tail), "sample_topk_advance")
             return
         # Not taken by any BASELINE configuration (GLM-4's 151,552 logits are native since round 3).  torch.topk's
         # multi-block path faulted under hipGraph replay in round 1 (profiles/r02_graph_fault_record.txt): a captured

@@ -59,15 +59,31 @@ def linear_decode(x, w, bias=None, fuse_silu_mul=False, out=None):
     return y
 
 
-def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False, out=None, h_out=None):
+def range_max_supported(x_numel, K, N):
+    """Whether norm_linear_decode(..., range_max=) takes the one-launch path that fills the sampler's range keys."""
+    return x_numel == K == 4096 and N % 16 == 0 and N // 16 <= 16384
+
+
+def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False, out=None, h_out=None, range_max=None):
     """(h, y): h = x + residual (residual None -> h = x), y = linear(RMSNorm(h) * norm_w) for one token, one
     native launch when the hidden size is 4096; otherwise add_rmsnorm + linear_decode.  out / h_out: caller-owned
-    result buffers (the eager decode paths reuse theirs instead of allocating per call)."""
+    result buffers (the eager decode paths reuse theirs instead of allocating per call).
+    range_max (lm_head only; int16 [>= N // 16], 16-B aligned; range_max_supported(...) must hold): the launch also leaves the
+    largest of every 16 outputs as the sampler's 16-bit key (sample_token_native(..., range_max=))."""
     K = x.shape[-1]
+    N = w.shape[0]
+    if range_max is not None:
+        if fuse_silu_mul or not range_max_supported(x.numel(), K, N) or not x.is_contiguous() or not w.is_contiguous():
+            raise ValueError("range_max: one token, hidden size 4096, N % 16 == 0, N <= 262,144, no fused SiLU")
+        y = out if out is not None else torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        h = (h_out if h_out is not None else torch.empty_like(x)) if residual is not None else x
+        check(lib().skv_norm_gemv_rangemax_bf16(ptr(w), ptr(x), ptr(residual), ptr(norm_w), float(eps),
+                                                ptr(h) if residual is not None else 0, ptr(bias), ptr(y), N, K, ptr(range_max),
+                                                current_stream_handle()), "norm_gemv_rangemax")
+        return h, y
     if x.numel() != K or K != 4096 or not x.is_contiguous() or not w.is_contiguous():
         h, hs = add_rmsnorm(x, residual, norm_w, eps)
         return h, linear_decode(hs, w, bias, fuse_silu_mul, out=out)
-    N = w.shape[0]
     y = out if out is not None else torch.empty(x.shape[:-1] + ((N // 2) if fuse_silu_mul else N,), dtype=x.dtype, device=x.device)
     h = (h_out if h_out is not None else torch.empty_like(x)) if residual is not None else x
     check(lib().skv_norm_gemv_bf16(ptr(w), ptr(x), ptr(residual), ptr(norm_w), float(eps),
@@ -330,13 +346,15 @@ def set_sampler_seed(seed):
     _sampler_seed = None if seed is None else int(seed)
 
 
-def sample_token_native(logits, temperature, top_k, top_p, seed=None, state=None):
+def sample_token_native(logits, temperature, top_k, top_p, seed=None, state=None, range_max=None):
     """sample_token in ONE native launch for bf16 logits [bs, V] on the GPU (skv_sample_topk_advance: exact k-th value,
     every logit tied with it kept - the reference's filter -, logit / temperature, nucleus, draw).  Same distribution as
     the torch pipeline below; the random numbers are NOT torch's generator stream: they come from a counter-based hash of
     (seed, draw counter, row) with seed = `seed`, else set_sampler_seed(), else torch.initial_seed() (so torch.manual_seed
     reseeds it), and a draw counter kept per `state` (any dict a caller owns - one per model or generation - default: one
-    per (device, batch size) of the process).  Returns None when the kernel does not take the row (caller falls back)."""
+    per (device, batch size) of the process).  Returns None when the kernel does not take the row (caller falls back).
+    range_max (int16 [bs, >= V // 16], from norm_linear_decode(..., range_max=) of the SAME logits): the sampler reads the
+    keys and the ~k ranges that can hold a winner instead of the whole row - same token."""
     bs, V = logits.shape
     k = min(top_k, V) if top_k > 0 else V
     if not (logits.is_cuda and logits.dtype == torch.bfloat16 and temperature > 0.0 and 1 <= k <= 64 and V % 8 == 0
@@ -359,19 +377,26 @@ def sample_token_native(logits, temperature, top_k, top_p, seed=None, state=None
         st["pos"].zero_()
         st["seed"] = seed
     token = torch.empty(bs, 1, dtype=torch.long, device=logits.device)
+    if range_max is not None and V % 16 == 0 and V // 16 <= 16384 and V // 16 >= k:
+        rm = range_max.view(bs, -1)
+        check(lib().skv_sample_topk_advance_ranges(ptr(logits), logits.stride(0), V, ptr(rm), rm.stride(0), bs, k, float(temperature),
+                                                   float(top_p), seed, ptr(token), ptr(st["pos"]), ptr(st["gen"]), ptr(st["row"]),
+                                                   ptr(st["kvl"]), 0, 0, 1, 1, 0, 0, 0, current_stream_handle()),
+              "sample_topk_advance_ranges")
+        return token
     check(lib().skv_sample_topk_advance(ptr(logits), logits.stride(0), V, bs, k, float(temperature), float(top_p), seed,
                                         ptr(token), ptr(st["pos"]), ptr(st["gen"]), ptr(st["row"]), ptr(st["kvl"]), 0, 0, 1, 1,
                                         0, 0, 0, current_stream_handle()), "sample_topk_advance")
     return token
 
 
-def sample_token(logits, temperature=0, top_k=50, top_p=0.9, state=None):
+def sample_token(logits, temperature=0, top_k=50, top_p=0.9, state=None, range_max=None):
     """tensor_op.py:291-297.  bf16 logits on the GPU take the native sampler, whose random numbers are not torch's generator
     stream (see sample_token_native: seeded from torch.initial_seed() / set_sampler_seed, draw counter per `state`)."""
     if temperature == 0.0:
         return logits.argmax(dim=-1, keepdim=True)
     if logits.dtype == torch.bfloat16 and logits.is_cuda:     # the lm_head's own output: one native launch
-        tok = sample_token_native(logits, temperature, top_k, top_p, state=state)
+        tok = sample_token_native(logits, temperature, top_k, top_p, state=state, range_max=range_max)
         if tok is not None:
             return tok
         logits = logits.float()

@@ -935,3 +935,76 @@ def test_reference_shaped_methods_on_the_in_place_layout(glm):
     # same chunk sets as the reference's slot order (which greedy token follows may differ: the order of the attention's sums does)
     if outs[0] == outs[1]:
         assert torch.equal(m2.kv_cache.position_ids.sort(dim=-1).values, m3.kv_cache.position_ids.sort(dim=-1).values)
+
+
+def _order_keys(bf16_row):
+    """The sampler's order-preserving 16-bit key of bf16 values (x >= 0: x | 0x8000; x < 0: ~x), as int32."""
+    b = bf16_row.view(torch.int16).to(torch.int32) & 0xffff
+    return torch.where((b & 0x8000) != 0, (~b) & 0xffff, b | 0x8000)
+
+
+@pytest.mark.parametrize("V", [128256, 151552, 64000, 2000 * 16])
+def test_lm_head_range_maxima_and_the_sampler_that_reads_them(V):
+    """Round 4: the lm_head launch leaves the largest of every 16 logits as a 16-bit key (skv_norm_gemv_rangemax_bf16) and the
+    sampler finds the ranges that can hold a top-k logit from those keys instead of streaming the row through one CU
+    (skv_sample_topk_advance_ranges).  Logits and residual stream equal the plain launch's bit for bit; the keys equal the
+    maxima computed with torch; the token drawn equals the streaming sampler's - on random rows, rows with hundreds of logits
+    tied at the top (more qualifying ranges than the candidate buffer holds: the kernel streams the row), an all-equal row,
+    k = 1 / 50 / 64."""
+    from shadowkv_amd import tensor_op
+    g = torch.Generator(device=DEV).manual_seed(V)
+    W = (torch.randn(V, 4096, device=DEV, generator=g) * 0.02).bfloat16()
+    x = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    res = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    nw = (1.0 + 0.1 * torch.randn(4096, device=DEV, generator=g)).bfloat16()
+    h1, y1 = tensor_op.norm_linear_decode(x, res, nw, 1e-5, W)
+    rm = torch.full((1, (V // 16 + 7) // 8 * 8), -1, dtype=torch.int16, device=DEV)
+    h2, y2 = tensor_op.norm_linear_decode(x, res, nw, 1e-5, W, range_max=rm)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)) and torch.equal(h1.view(torch.int16), h2.view(torch.int16))
+    want = _order_keys(y1.view(-1)).view(V // 16, 16).max(dim=-1).values
+    assert torch.equal(rm[0, :V // 16].to(torch.int32) & 0xffff, want)
+    assert bool((rm[0, V // 16:] == -1).all())                               # nothing written past the last range
+
+    def keys_of(row):
+        out = torch.zeros(1, (V // 16 + 7) // 8 * 8, dtype=torch.int16, device=DEV)
+        out[0, :V // 16] = _order_keys(row.view(-1)).view(V // 16, 16).max(dim=-1).values.to(torch.int16)
+        return out
+
+    base = (y1.view(1, V).float() * 8.0).bfloat16()
+    rows = {"random": base}
+    tied = base.clone(); tied[0, torch.randperm(V, generator=torch.Generator().manual_seed(1))[:300].to(DEV)] = base.max() + 1.0
+    rows["300 tied at the top"] = tied
+    tied2 = base.clone(); tied2[0, ::7] = base.max() + 0.5                  # thousands of ties: > 128 ranges qualify -> streamed
+    rows["every 7th tied"] = tied2
+    rows["all equal"] = torch.full_like(base, -1.25)
+    neg = (-base.float().abs() - 3.0).bfloat16()
+    rows["all negative"] = neg
+    for name, row in rows.items():
+        for k in (1, 50, 64):
+            for trial in range(3):
+                a = tensor_op.sample_token_native(row, 0.6, k, 0.9, seed=100 + trial, state={})
+                b = tensor_op.sample_token_native(row, 0.6, k, 0.9, seed=100 + trial, state={}, range_max=keys_of(row))
+                torch.cuda.synchronize()
+                assert a is not None and b is not None and torch.equal(a, b), (name, k, trial, int(a), int(b))
+
+
+def test_decode_with_range_maxima_draws_the_same_tokens():
+    """The captured step with the lm_head's range maxima feeding the sampler (model.sampler_ranges, the default) against the
+    same step with the streaming sampler: same tokens."""
+    from shadowkv_amd import llama
+    cfg = llama.ModelConfig(name="h4096", hidden_size=4096, intermediate_size=2048, num_hidden_layers=2,
+                            num_attention_heads=32, num_key_value_heads=8, vocab_size=32000)
+    toks = {}
+    for ranges in (True, False):
+        m = llama.DecoderLM(cfg=cfg, batch_size=1, max_length=4608, device=DEV, sparse_budget=256, rank=160, chunk_size=8,
+                            seed=5, chunk_layout="inplace", overlap_attention=True)
+        llama.build_synthetic_context(m, 4608, seed=77)
+        m.sampler_ranges = ranges
+        table = llama.make_walk_table(m, 10, seed=3)
+        dec = llama.GraphDecoder(m, temperature=0.8, walk_table=table)
+        dec.token.copy_(torch.tensor([[17]], device=DEV))
+        dec.capture(warmup=2)
+        toks[ranges] = [int(dec.step()) for _ in range(10)]
+        assert (m._last_range_max is not None) == ranges
+    assert toks[True] == toks[False] and len(set(toks[True])) > 1

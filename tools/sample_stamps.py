@@ -10,6 +10,7 @@ from shadowkv_amd import _lib, tensor_op
 
 def main():
     V = int(sys.argv[1]) if len(sys.argv) > 1 else 128256
+    ranges = len(sys.argv) > 2 and sys.argv[2] == "ranges"
     L = _lib.lib()
     L.skv_debug_sample_stamps.argtypes = [ctypes.c_void_p]
     g = torch.Generator(device="cuda:0").manual_seed(1)
@@ -21,7 +22,16 @@ def main():
         flush.fill_(it)
         torch.cuda.synchronize()
         e0.record()
-        tok = tensor_op.sample_token_native(logits, 0.6, 50, 0.9, seed=7)
+        rm = None
+        if ranges:     # the keys the lm_head launch would have left (computed with torch here)
+            b = logits.view(torch.int16).to(torch.int32).view(-1) & 0xffff
+            keys = torch.where((b & 0x8000) != 0, (~b) & 0xffff, b | 0x8000).view(V // 16, 16).max(dim=-1).values
+            rm = torch.zeros(1, (V // 16 + 7) // 8 * 8, dtype=torch.int16, device="cuda:0")
+            rm[0, :V // 16] = keys.to(torch.int16)
+            flush.fill_(it + 100)
+            torch.cuda.synchronize()
+            e0.record()
+        tok = tensor_op.sample_token_native(logits, 0.6, 50, 0.9, seed=7, range_max=rm)
         e1.record()
         torch.cuda.synchronize()
         L.skv_debug_sample_stamps(buf.ctypes.data)
