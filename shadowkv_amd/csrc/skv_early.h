@@ -21,9 +21,18 @@
 // (bounded by E), a missing one is fetched as before.
 #pragma once
 #include "skv_common.h"
+#include "skv_select_front.h"
 #include "skv_launch.h"
 #ifndef PULL_STAMP
 #define PULL_STAMP(i)
+#endif
+#ifdef SKV_TOPK_STAMPS     // the list role's phases, first pull workgroup of the launch (tools/topk_stamps.py)
+#define PREP_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        if (b == 0 && part == 0 && s_list != nullptr && tid == 0) g_topk_stamps[i] = wall_clock64();    \
+    } while (0)
+#else
+#define PREP_STAMP(i)
 #endif
 
 #define EF_MAX_E 128
@@ -101,6 +110,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (my_res[k] >= 0 && my_res[k] < n_chunks) atomicOr(&s_bits[my_res[k] >> 5], 1 << (my_res[k] & 31));
+    PREP_STAMP(19);
     // ---- round trip 2: slot -> chunk id
     long long id[CPT];
     unsigned realm = 0;
@@ -122,7 +132,9 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
             }
         }
     }
+    PREP_STAMP(20);
     __syncthreads();                                       // the bitmap is complete
+    PREP_STAMP(21);
     int nkeep = 0;
     unsigned keepm = 0;
 #pragma unroll
@@ -133,7 +145,12 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clears above are in L2)
-    const int kincl = ef_block_scan_incl<THREADS>(nkeep, s_w, tid);
+    PREP_STAMP(22);
+    // (1,024 threads: the selection's DPP scan with ONE barrier - the shuffle scan above took 1.1 of the list's 4.2 us, in-step stamps)
+    int kincl;
+    if constexpr (THREADS == T2_THREADS) kincl = block_scan_incl1(nkeep, s_w, tid);
+    else kincl = ef_block_scan_incl<THREADS>(nkeep, s_w, tid);
+    PREP_STAMP(23);
     if (tid == THREADS - 1) {
         if (part == 0) eh.early_cnt[b] = min(kincl, E);
         if (s_list) s_list[EF_MAX_E] = min(kincl, E);

@@ -34,6 +34,7 @@ def main():
         misses = int(cache.block_num * cache.select_sets - int(cache.cnts.sum()))
         print(f"step {it}: misses {misses} pulled {int(cache.early_fetch_counts(0).sum())} | select WG: start {r(0):.2f} finals {r(12):.2f} level {r(13):.2f} "
               f"(search {r(14) - r(13):.2f}) gather+exact {r(16):.2f} search2 {r(17):.2f} placed {r(18):.2f} ids {r(6):.2f} lookup {r(7):.2f} "
-              f"scan3 {r(8):.2f} vote {r(9):.2f} end {r(10):.2f} | pull WG 0: start {r(24):.2f} list ready {r(25):.2f} pulled {r(26):.2f}")
+              f"scan3 {r(8):.2f} vote {r(9):.2f} end {r(10):.2f} | pull WG 0: start {r(24):.2f} [resident ids in {r(19):.2f} slot ids {r(20):.2f} "
+              f"barrier {r(21):.2f} clears acked {r(22):.2f} scan {r(23):.2f}] list ready {r(25):.2f} pulled {r(26):.2f}")
 
 main()
