@@ -20,6 +20,18 @@
 #include "skv_early.h"
 
 #define SKV_TILE 256  // columns per partial tile == the reference's ThreadblockShape::kN
+// per-wave phase stamps of the scan (tools/score_probe.hip builds with -DSKV_SCORE_STAMPS; never in the library):
+// g_score_stamps[(workgroup * 16 + wave) * 8 + i], 100 MHz wall clock, lane 0 of every wave
+#ifdef SKV_SCORE_STAMPS
+__device__ unsigned long long* g_score_stamps;
+#define SCORE_STAMP(i)                                                                                                      \
+    do {                                                                                                                    \
+        if (g_score_stamps != nullptr && (threadIdx.x & 63) == 0)                                                           \
+            g_score_stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define SCORE_STAMP(i)
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
@@ -35,6 +47,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef SKV_SCORE_WAVES
 #define SKV_SCORE_WAVES 16                      // waves per 256-landmark tile (16 rows each; 4/8/16 measured: 9.3 / 8.8 / 8.5 us)
 #endif
+// waves per SIMD the register allocation aims at: two workgroups per CU (8 per SIMD at 16 waves per tile and G <= 4: 64 VGPRs; 4 at
+// 8 waves: 128; 2 at 4 waves: 256 - a wave that holds 16 row groups in flight needs them)
+#define SKV_SCORE_MIN_WAVES(G, WAVES) ((WAVES) >= 16 ? ((G) >= 8 ? 4 : 8) : (WAVES) >= 8 ? 4 : (WAVES) >= 4 ? 2 : 1)
 #ifndef SKV_SCORE_PD
 #define SKV_SCORE_PD 64                         // row-group loads a wave keeps in flight; >= ITERS: all up front (see the kernel comment)
 #endif
@@ -82,7 +97,7 @@ __device__ __forceinline__ void score_row_group(const f32x2 (&qf)[(GH + 1) / 2][
 // bit-identical: every head's total is the same fma chain and the same 16-lane tree whichever other heads travel through
 // the butterfly with it.
 template <int G, int ABL = 0, int WAVES = (G == 8 ? 8 : SKV_SCORE_WAVES), int PD = SKV_SCORE_PD>
-__global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void skv_score_tile_kernel(
+__global__ __launch_bounds__(64 * WAVES, SKV_SCORE_MIN_WAVES(G, WAVES)) void skv_score_tile_kernel(
     const bf16_t* __restrict__ q,    // [B][G][128]
     const bf16_t* __restrict__ lm,   // [B][N][128]
     bf16_t* __restrict__ D,          // [B][G][N]
@@ -153,15 +168,23 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         if (f == 0x12345u) D[0] = (bf16_t)f;
         return;
     }
+    SCORE_STAMP(0);
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         // program order: request row group i + DEPTH, then consume row group i (the compiler's counted vmcnt wait leaves the
         // DEPTH younger requests in flight); the scheduling barriers keep hipcc from hoisting every request to the top again
         if (i + DEPTH < ITERS) request(i + DEPTH);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef SKV_SCORE_STAMPS
+        if (i == 0 || i == ITERS - 1) {          // when the first / the last row group's data is there
+            if (x[i][0] == 0x12345678u) sD[0][0] = 1;
+            SCORE_STAMP(i == 0 ? 1 : 2);
+        }
+#endif
         score_row_group<GH>(qf, x[i], &sD[0][0], wave * (4 * ITERS) + i * 4 + rsel, lane, alpha);
         __builtin_amdgcn_sched_barrier(0);
     }
+    SCORE_STAMP(3);
     if constexpr (PASSES > 1) {
 #pragma unroll
         for (int p = 1; p < PASSES; ++p) {
@@ -183,6 +206,7 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
         }
     }
     __syncthreads();
+    SCORE_STAMP(4);
     if (ABL == 2) {
         if (tid < SKV_TILE && t * SKV_TILE + tid < N) {
 #pragma unroll
@@ -284,6 +308,7 @@ __global__ __launch_bounds__(64 * WAVES, G >= 8 ? 4 : WAVES >= 8 ? 8 : 4) void s
             part_sum[((size_t)b * T + t) * G + g] = fixed_to_float(e);
         }
     }
+    SCORE_STAMP(5);
 }
 
 // final (max, 1/sum) of one softmax row from its T tile partials; executed by one full wave.

@@ -3,6 +3,9 @@
 // (Llama 122K: B = 8, G = 4, N = 15,560; GLM 200K: B = 4, G = 8, N = 25,544).  Every variant cycles over 32 landmark
 // tables (1 GB: far beyond the Infinity Cache), interleaved rounds in one process, median of the rounds.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I shadowkv_amd/csrc tools/score_probe.hip -o /tmp/score_probe
+#ifdef PROBE_STAMPS
+#define SKV_SCORE_STAMPS
+#endif
 #include "../shadowkv_amd/csrc/skv_select.hip"
 #include <stdio.h>
 #include <algorithm>
@@ -43,6 +46,41 @@ static void bench(std::vector<Variant>& vs, std::vector<bf16_t*>& tabs, double m
     }
 }
 
+#ifdef PROBE_STAMPS
+// per-wave phase stamps of one launch of variant v: where the launch's time goes (us since the first wave's start)
+static void stamp_report(Variant& v, const bf16_t* tab, int n_wg, int waves, const char* title) {
+    unsigned long long* d; hipMalloc(&d, (size_t)n_wg * 16 * 8 * 8); hipMemset(d, 0, (size_t)n_wg * 16 * 8 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_score_stamps), &d, sizeof(d));
+    for (int w = 0; w < 3; ++w) { v.launch(tab); hipDeviceSynchronize(); }
+    std::vector<unsigned long long> h((size_t)n_wg * 16 * 8);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long* z = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(g_score_stamps), &z, sizeof(z)); hipFree(d);
+    unsigned long long t0 = ~0ull;
+    for (int g = 0; g < n_wg; ++g) for (int w = 0; w < waves; ++w) { auto x = h[((size_t)g * 16 + w) * 8]; if (x && x < t0) t0 = x; }
+    const char* names[6] = {"loads issued", "first row group's data", "last row group's data", "dot products done", "behind the barrier", "statistics done"};
+    printf("%s: per-wave stamps, us since the first wave's start (min / median / p90 / max over %d waves)\n", title, n_wg * waves);
+    for (int i = 0; i < 6; ++i) {
+        std::vector<float> a;
+        for (int g = 0; g < n_wg; ++g) for (int w = 0; w < waves; ++w) { auto x = h[((size_t)g * 16 + w) * 8 + i]; if (x) a.push_back((x - t0) / 100.0f); }
+        if (a.empty()) continue;
+        std::sort(a.begin(), a.end());
+        printf("   %-26s %6.2f / %6.2f / %6.2f / %6.2f\n", names[i], a[0], a[a.size() / 2], a[a.size() * 9 / 10], a.back());
+    }
+    // per workgroup: when its LAST wave has its last data, when it passes the barrier, when its last wave ends
+    std::vector<float> wl, wb, we;
+    for (int g = 0; g < n_wg; ++g) {
+        unsigned long long l = 0, bb = 0, e = 0;
+        for (int w = 0; w < waves; ++w) { l = std::max(l, h[((size_t)g * 16 + w) * 8 + 2]); bb = std::max(bb, h[((size_t)g * 16 + w) * 8 + 4]); e = std::max(e, h[((size_t)g * 16 + w) * 8 + 5]); }
+        wl.push_back((l - t0) / 100.0f); wb.push_back((bb - t0) / 100.0f); we.push_back((e - t0) / 100.0f);
+    }
+    auto pr = [](const char* n, std::vector<float>& a) { std::sort(a.begin(), a.end()); printf("   per workgroup: %-22s %6.2f / %6.2f / %6.2f / %6.2f\n", n, a[0], a[a.size() / 2], a[a.size() * 9 / 10], a.back()); };
+    pr("last data", wl); pr("barrier passed", wb); pr("last wave done", we);
+}
+
+#else
+static void stamp_report(Variant&, const bf16_t*, int, int, const char*) {}
+#endif
+
 int main() {
     {
         const int B = 8, G = 4, N = 15560, T = (N + 255) / 256;
@@ -52,19 +90,17 @@ int main() {
         hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
         hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
         std::vector<Variant> vs;
-        vs.push_back(make<4, 0, 16, 4>("G4 16 waves, all 4 loads up front (r2)", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 16, 1>("G4 16 waves, depth 1", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 16, 2>("G4 16 waves, depth 2", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 16, 3>("G4 16 waves, depth 3", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 8, 2>("G4  8 waves, depth 2", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 8, 3>("G4  8 waves, depth 3", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 8, 4>("G4  8 waves, depth 4", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 4, 4>("G4  4 waves, depth 4", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 4, 6>("G4  4 waves, depth 6", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 1, 16, 4>("G4 16 waves, loads only, all up front", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 1, 16, 2>("G4 16 waves, loads only, depth 2", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 2, 16, 2>("G4 16 waves, depth 2, no statistics tail", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 16, 4>("G4 16 waves x 4 row groups (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 8, 8>("G4  8 waves x 8 row groups, 128 VGPRs", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 4, 16>("G4  4 waves x 16 row groups, 256 VGPRs", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 2, 32>("G4  2 waves x 32 row groups", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 1, 16, 4>("G4 16 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 1, 8, 8>("G4  8 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 1, 4, 16>("G4  4 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 1, 2, 32>("G4  2 waves, loads only", q, D, pm, ps, B, N, T));
         bench(vs, tabs, (double)B * N * 256 / 1e6, "Llama-3.1-8B 122K: B 8, G 4, N 15560, 488 tiles");
+        stamp_report(vs[0], tabs[5], T * B, 16, "G4 16 waves");
+        stamp_report(vs[2], tabs[5], T * B, 4, "G4 4 waves");
         for (auto t : tabs) hipFree(t);
         hipFree(q); hipFree(D); hipFree(pm); hipFree(ps);
     }
@@ -76,21 +112,18 @@ int main() {
         hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
         hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
         std::vector<Variant> vs;
-        vs.push_back(make<8, 0, 8, 8>("G8  8 waves, all 8 loads up front (r2)", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 8, 2>("G8  8 waves, depth 2", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 8, 3>("G8  8 waves, depth 3", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 8, 4>("G8  8 waves, depth 4", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 8, 6>("G8  8 waves, depth 6", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 16, 2>("G8 16 waves (one tile per CU), depth 2", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 16, 4>("G8 16 waves (one tile per CU), all up front", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 4, 4>("G8  4 waves, depth 4", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 4, 8>("G8  4 waves, depth 8", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 1, 8, 8>("G8  8 waves, loads only, all up front", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 1, 8, 3>("G8  8 waves, loads only, depth 3", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 2, 8, 3>("G8  8 waves, depth 3, no statistics tail", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 8, 8>("G8  8 waves x 8 row groups (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 4, 16>("G8  4 waves x 16 row groups, 256 VGPRs", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 2, 32>("G8  2 waves x 32 row groups", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 1, 8, 8>("G8  8 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 1, 4, 16>("G8  4 waves, loads only", q, D, pm, ps, B, N, T));
         bench(vs, tabs, (double)B * N * 256 / 1e6, "GLM-4-9B 200K: B 4, G 8, N 25544, 400 tiles");
+        stamp_report(vs[0], tabs[5], T * B, 8, "G8 8 waves");
+        stamp_report(vs[1], tabs[5], T * B, 4, "G8 4 waves");
+        for (auto t : tabs) hipFree(t);
+        hipFree(q); hipFree(D); hipFree(pm); hipFree(ps);
     }
-    {   // Yi-9B-200K at 122K / Llama 60K-style shapes: fewer tiles than CUs - one tile's latency chain
+    {
         const int B = 4, G = 8, N = 15560, T = (N + 255) / 256;
         std::vector<bf16_t*> tabs(48);
         for (auto& t : tabs) { hipMalloc(&t, (size_t)B * N * 256); hipMemset(t, 0x3c, (size_t)B * N * 256); }
@@ -98,10 +131,9 @@ int main() {
         hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
         hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
         std::vector<Variant> vs;
-        vs.push_back(make<8, 0, 8, 8>("G8  8 waves, all up front (shipped)", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 0, 16, 4>("G8 16 waves, all up front", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 1, 8, 8>("G8  8 waves, loads only", q, D, pm, ps, B, N, T));
-        vs.push_back(make<8, 1, 16, 4>("G8 16 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 8, 8>("G8  8 waves (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 16, 4>("G8 16 waves", q, D, pm, ps, B, N, T));
+        vs.push_back(make<8, 0, 4, 16>("G8  4 waves", q, D, pm, ps, B, N, T));
         bench(vs, tabs, (double)B * N * 256 / 1e6, "Yi-9B 122K: B 4, G 8, N 15560, 244 tiles");
         for (auto t : tabs) hipFree(t);
         hipFree(q); hipFree(D); hipFree(pm); hipFree(ps);
@@ -114,9 +146,9 @@ int main() {
         hipMalloc(&q, B * G * 256); hipMemset(q, 0x3c, B * G * 256); hipMalloc(&D, (size_t)B * G * N * 2);
         hipMalloc(&pm, B * T * G * 4); hipMalloc(&ps, B * T * G * 4);
         std::vector<Variant> vs;
-        vs.push_back(make<4, 0, 16, 4>("G4 16 waves, all up front (shipped)", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 0, 8, 8>("G4  8 waves, all up front", q, D, pm, ps, B, N, T));
-        vs.push_back(make<4, 1, 16, 4>("G4 16 waves, loads only", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 16, 4>("G4 16 waves (shipped)", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 8, 8>("G4  8 waves", q, D, pm, ps, B, N, T));
+        vs.push_back(make<4, 0, 4, 16>("G4  4 waves", q, D, pm, ps, B, N, T));
         bench(vs, tabs, (double)B * N * 256 / 1e6, "Llama 60K: B 8, G 4, N 7672, 240 tiles");
     }
     return 0;
