@@ -81,7 +81,51 @@ static void stamp_report(Variant& v, const bf16_t* tab, int n_wg, int waves, con
 static void stamp_report(Variant&, const bf16_t*, int, int, const char*) {}
 #endif
 
+// Pure stream of `total` bytes: workgroups of WAVES waves, every wave LOADS coalesced 1-KiB loads issued up front, folded and dropped.
+// Same bytes, different numbers of workgroups / waves: what part of the scan's "loads-only" time is dispatch and what is bandwidth.
+template <int WAVES, int LOADS>
+__global__ __launch_bounds__(64 * WAVES) void probe_stream_kernel(const u32x4* __restrict__ src, size_t n_vec, uint32_t* sink) {
+    const size_t base = ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * LOADS * 64 + (threadIdx.x & 63);
+    u32x4 x[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        size_t v = base + (size_t)i * 64;
+        x[i] = __builtin_nontemporal_load(src + (v < n_vec ? v : n_vec - 1));
+    }
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) f ^= x[i][0] ^ x[i][1] ^ x[i][2] ^ x[i][3];
+    if (f == 0x12345u) *sink = f;
+}
+template <int WAVES, int LOADS>
+static Variant make_stream(const char* name, size_t bytes, uint32_t* sink) {
+    const size_t n_vec = bytes / 16, per_wg = (size_t)WAVES * LOADS * 64;
+    const int grid = (int)((n_vec + per_wg - 1) / per_wg);
+    char buf[128]; snprintf(buf, sizeof buf, "%s (%d workgroups, %d waves)", name, grid, grid * WAVES);
+    return Variant{buf, [=](const bf16_t* tab) {
+        hipLaunchKernelGGL((probe_stream_kernel<WAVES, LOADS>), dim3(grid), dim3(64 * WAVES), 0, 0, (const u32x4*)tab, n_vec, sink);
+    }, {}};
+}
+
 int main() {
+    {
+        const size_t bytes = (size_t)8 * 15560 * 256;
+        std::vector<bf16_t*> tabs(32);
+        for (auto& t : tabs) { hipMalloc(&t, bytes); hipMemset(t, 0x3c, bytes); }
+        uint32_t* sink; hipMalloc(&sink, 4);
+        std::vector<Variant> vs;
+        vs.push_back(make_stream<16, 4>("16 waves x 4 KiB", bytes, sink));
+        vs.push_back(make_stream<16, 8>("16 waves x 8 KiB", bytes, sink));
+        vs.push_back(make_stream<16, 16>("16 waves x 16 KiB", bytes, sink));
+        vs.push_back(make_stream<8, 8>(" 8 waves x 8 KiB", bytes, sink));
+        vs.push_back(make_stream<8, 16>(" 8 waves x 16 KiB", bytes, sink));
+        vs.push_back(make_stream<4, 16>(" 4 waves x 16 KiB", bytes, sink));
+        vs.push_back(make_stream<4, 32>(" 4 waves x 32 KiB", bytes, sink));
+        vs.push_back(make_stream<4, 4>(" 4 waves x 4 KiB", bytes, sink));
+        vs.push_back(make_stream<1, 16>(" 1 wave  x 16 KiB", bytes, sink));
+        bench(vs, tabs, bytes / 1e6, "pure stream of 31.87 MB");
+        for (auto t : tabs) hipFree(t);
+    }
     {
         const int B = 8, G = 4, N = 15560, T = (N + 255) / 256;
         std::vector<bf16_t*> tabs(32);
