@@ -739,10 +739,11 @@ class ShadowKVCache_CPU:
         to `early_max` of their non-resident chunks per head, an extra workgroup of the top-k launch pulls those from the
         pinned host table while the top-k runs, and the fetch launch reads them from HBM.  Same results bit for bit; a wrong guess costs PCIe bytes only.
         early_max None: what the link moves while the top-k launch runs at the shape - 32 chunks per head for G <= 4 and 64 for
-        G = 8 at 256 selected chunks per head, scaled with the selection (budget 4096: 64 / 128; budget 1024: 24 / 48) - swept on
+        G = 8 at 256 selected chunks per head, 1.5x per selected chunk beside it (budget 4096: 96 / 128; budget 1024: 24 / 48) - swept on
         MI355X with the fused selection (profiles/r04_fused_selection.txt: 28 / 32 / 40 / 56 chunks 222.5 / 224.8 / 224.4 / 224.1
-        tokens/s at config 1; 64 / 80 194.2 / 191.7 at config 3; 28 / 40 / 56 / 72 160.9 / 164.4 / 169.4 / 172.7 at 244K with budget
-        4096; 20 / 28 / 40 257.3 / 257.8 / 252.2 at 60K with budget 1024); 0 / False switches it off again."""
+        tokens/s at config 1; 48 / 64 / 80 198.0 / 198.0 / 195.2 at config 3; 48 / 64 / 96 / 112 / 128 173.0 / 174.2 / 179.7 / 179.9 /
+        177.7 at 244K with budget 4096 - its selection runs longer, more of the link's work fits beside it; 16 / 24 / 32 261.5 / 261.8 /
+        260.3 at 60K with budget 1024); 0 / False switches it off again."""
         if not early_max and early_max is not None:
             if self._early is not None:      # a captured step may still point at the state buffers: they stay allocated
                 self._early_retired = getattr(self, "_early_retired", []) + [self._early]
@@ -759,7 +760,7 @@ class ShadowKVCache_CPU:
             E = max(1, 256 // self.block_num)
         else:
             base = 32 if self.num_key_value_groups <= 4 else 64
-            E = base * self.select_sets // 256 if self.select_sets >= 256 else max(8, base * 3 * self.select_sets // (2 * 256))
+            E = base if self.select_sets == 256 else max(8, base * 3 * self.select_sets // (2 * 256))
         E = max(1, min(E, 128))
         n_lm, n_chunks = self.k_landmark.shape[-2], self.v_cache_cpu.shape[-2]
         nbytes = int(L.skv_early_state_bytes(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E))

@@ -23,7 +23,7 @@ DEV = "cuda:0"
 SHAPES = {"llama31_122k": ("LLAMA_3_1_8B", 124928, 2048, 15560, 32), "glm4_200k": ("GLM_4_9B_1M", 204800, 2048, 25544, 64),
           # the reference's 244K regime (test/e2e.py:50-55): budget 4096 -> S = 512, 96 outlier chunks, 122 scan tiles per head,
           # 64 miss tiles + 24 splits = 88 attention records per head
-          "llama31_244k_b4096": ("LLAMA_3_1_8B", 249856, 4096, 31128, 64)}
+          "llama31_244k_b4096": ("LLAMA_3_1_8B", 249856, 4096, 31128, 96)}
 REPLAYS = 6
 _RUNS = {}
 
@@ -58,7 +58,7 @@ def _run(shape, early):
 
 
 @pytest.fixture(scope="module", params=[("llama31_122k", False), ("llama31_122k", True), ("glm4_200k", True), ("llama31_244k_b4096", True)],
-                ids=["llama31_122k-plain", "llama31_122k-early32", "glm4_200k-early64", "llama31_244k_b4096-early64"])
+                ids=["llama31_122k-plain", "llama31_122k-early32", "glm4_200k-early64", "llama31_244k_b4096-early96"])
 def decoded(request):
     return _run(*request.param)[0]
 
