@@ -108,6 +108,8 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
     if not full:
         model.kv_cache.fused_select = bool(getattr(args, "fused_select", 1))
     model.sampler_ranges = bool(getattr(args, "sampler_ranges", 1))
+    if not full and getattr(args, "overlap_splits", 0):
+        model.kv_cache.OVERLAP_SPLITS = int(args.overlap_splits)
     if (not full and args.early_fetch and args.v_table == "host" and model.kv_cache.early_fetch_supported()
             and model.kv_cache.select_sets >= 128 and (args.batch == 1 or args.early_fetch_batches)):
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
@@ -770,6 +772,8 @@ def main(argv=None):
     ap.add_argument("--sampler-ranges", type=int, default=1, choices=[0, 1],
                     help="1 (default): the lm_head launch leaves the largest of every 16 logits, the sampler reads those keys and "
                          "the ~50 ranges that can hold a top-k logit (same token); 0: the sampler streams the whole logit row")
+    ap.add_argument("--overlap-splits", type=int, default=0,
+                    help="tuning: split-attention workgroups per head inside the fetch launch (0: the default, 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no sweep / secondary workloads)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short lines for BASELINE.json configs 2 and 3")
