@@ -389,17 +389,20 @@ SKV_EXPORT int skv_select_chunks_fused(const void* q, const void* landmarks, con
  * skv_select_chunks_inplace_early of the same step and state.
  * skv_early_state_offsets: byte offsets of the state's regions (diagnostics): 0 thresholds f32 [B][G], 1 finals f32
  * [B][G][2], 2 flag counts i32 [B][T], 3 flagged slots i32 [B][T][16], 4 pulled count i32 [B], 5 pulled chunk ids i32
- * [B][early_max], 6 staging index per chunk i16 [B][n_chunks], 7 staging [B][early_max][2048 B] (out8 holds TEN entries: 8, 9
- * see skv_early_state_set_landmark_map). */
+ * [B][early_max], 6 staging index per chunk i16 [B][n_chunks], 7 staging [B][early_max][2048 B] - EIGHT entries.
+ * skv_early_state_offsets2 writes the first n_out (<= SKV_EARLY_STATE_REGIONS) entries: 8, 9 see skv_early_state_set_landmark_map. */
+#define SKV_EARLY_STATE_REGIONS 10
 SKV_EXPORT size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chunks, int early_max);
 SKV_EXPORT int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8);
+SKV_EXPORT int skv_early_state_offsets2(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out,
+                                        int n_out);
 SKV_EXPORT int skv_early_state_init(void* state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,
                          skv_stream_t stream);
 /* Optional, once after skv_early_state_init (round 4): the head's slot -> chunk-id map in closed form.  The reference registers
  * every chunk but the outliers as a landmark, in ascending order (/root/reference/models/kv_cache.py:903-919), so the id of
  * slot j is j + (number of left-out chunks up to there): with the table of up to 127 such gaps the list role needs no dependent
  * gather of landmark_idx (one memory round trip less in front of the link, ~1 us per layer).  A landmark_idx of any other shape
- * (unsorted, more gaps) is detected here and keeps the gather.  skv_early_state_offsets then reports ten entries: 8 = the gap
+ * (unsorted, ids below their slot, more gaps) is detected here and keeps the gather.  skv_early_state_offsets2 reports them: 8 = the gap
  * table i32 [blocks][128], 9 = its validity flag i32 [blocks]. */
 SKV_EXPORT int skv_early_state_set_landmark_map(void* state, const int64_t* landmark_idx, int blocks, int groups, int n_landmarks,
                                      int n_chunks, int early_max, skv_stream_t stream);

@@ -51,6 +51,7 @@ _SIGS = {
     "skv_select_chunks_fused": (c_int, [c_p] * 9 + [c_int] * 5 + [c_p, c_f] + [c_p, c_p, c_p, c_ll, c_int, c_int, c_f, c_p]),
     "skv_early_state_bytes": (c_sz, [c_int] * 5),
     "skv_early_state_offsets": (c_int, [c_int] * 5 + [ctypes.POINTER(c_ll)]),
+    "skv_early_state_offsets2": (c_int, [c_int] * 5 + [ctypes.POINTER(c_ll), c_int]),
     "skv_early_state_init": (c_int, [c_p] + [c_int] * 5 + [c_p]),
     "skv_early_state_set_landmark_map": (c_int, [c_p, c_p] + [c_int] * 5 + [c_p]),
     "skv_select_chunks_inplace_early": (c_int, [c_p] * 10 + [c_int] * 5 + [c_p, c_f] + [c_p, c_p, c_ll, c_int, c_int, c_f] + [c_p]),

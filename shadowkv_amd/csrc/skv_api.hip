@@ -302,17 +302,27 @@ size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chun
     return skv_carve_early(nullptr, blocks, groups, n_landmarks, n_chunks, early_max).total;
 }
 
-int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8) {
-    if (!out8 || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
-    // (out8: ten entries since round 4 - 8: the slot -> chunk-id gap table i32 [B][128], 9: its validity flag i32 [B])
+static int early_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out, int n_out) {
+    if (!out || n_out < 0 || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     const EarlyState e = skv_carve_early(nullptr, blocks, groups, n_landmarks, n_chunks, early_max);
     const unsigned char* z = nullptr;
-    out8[0] = (const unsigned char*)e.dthr - z;      out8[1] = (const unsigned char*)e.finals - z;
-    out8[2] = (const unsigned char*)e.flag_cnt - z;  out8[3] = (const unsigned char*)e.flag_slot - z;
-    out8[4] = (const unsigned char*)e.early_cnt - z; out8[5] = (const unsigned char*)e.early_ids - z;
-    out8[6] = (const unsigned char*)e.early_of - z;  out8[7] = (const unsigned char*)e.staging - z;
-    out8[8] = (const unsigned char*)e.gap_slots - z; out8[9] = (const unsigned char*)e.map_ok - z;
+    const long long all[SKV_EARLY_STATE_REGIONS] = {
+        (const unsigned char*)e.dthr - z,      (const unsigned char*)e.finals - z,    (const unsigned char*)e.flag_cnt - z,
+        (const unsigned char*)e.flag_slot - z, (const unsigned char*)e.early_cnt - z, (const unsigned char*)e.early_ids - z,
+        (const unsigned char*)e.early_of - z,  (const unsigned char*)e.staging - z,   (const unsigned char*)e.gap_slots - z,
+        (const unsigned char*)e.map_ok - z};
+    for (int i = 0; i < n_out && i < SKV_EARLY_STATE_REGIONS; ++i) out[i] = all[i];
     return SKV_OK;
+}
+
+// eight entries, the round-3 contract of this name (a caller built against it passes an 8-entry array)
+int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8) {
+    return early_offsets(blocks, groups, n_landmarks, n_chunks, early_max, out8, 8);
+}
+
+// the first n_out (<= SKV_EARLY_STATE_REGIONS = 10) entries: 8 = the slot -> chunk-id gap table i32 [B][128], 9 = its validity flag
+int skv_early_state_offsets2(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out, int n_out) {
+    return early_offsets(blocks, groups, n_landmarks, n_chunks, early_max, out, n_out);
 }
 
 int skv_early_state_init(void* state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,

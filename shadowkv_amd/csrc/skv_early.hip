@@ -27,7 +27,9 @@ __global__ __launch_bounds__(1024) void skv_early_map_kernel(const int64_t* __re
     __syncthreads();
     for (int j = tid; j < N; j += 1024) {
         const long long d = lm_idx[(size_t)b * N + j] - j, dp = j > 0 ? lm_idx[(size_t)b * N + j - 1] - (j - 1) : 0;
-        if (d < dp || d < 0 || d >= SKV_EARLY_GAPS) s_bad = 1;      // (the list role's binary search counts up to GAPS - 1)
+        // both ends of the run [dp, d) are checked: an id below its slot index (duplicates, zeros) makes dp negative while d
+        // may still be in range - the store loop must not start in front of this head's table
+        if (d < dp || dp < 0 || d < 0 || d >= SKV_EARLY_GAPS) s_bad = 1;      // (the list role's binary search counts up to GAPS - 1)
         else
             for (long long i = dp; i < d; ++i) gap_slots[(size_t)b * SKV_EARLY_GAPS + i] = j;
     }

@@ -44,6 +44,7 @@ import torch
 
 from . import tensor_op
 from ._lib import lib, check, ptr, current_stream_handle
+from .kernels import shadowkv
 
 
 def pinned_host_tensor(shape, dtype):
@@ -223,8 +224,8 @@ class ShadowKVCache_CPU:
         # staging buffers of the two-phase (spin-free) chunk movement: moved hit chunks of one layer.  `temp` is the
         # reference's attribute of the same shape (kv_cache.py:612-620) and IS the V staging buffer; `output` is the
         # pre-RoPE K scratch of the reference's two-launch key path (kv_cache.py:637-645), unused by the fused path.
-        self._temp_k = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
-        self._temp_v = torch.empty(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
+        self._temp_k = torch.zeros(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
+        self._temp_v = torch.zeros(self.block_num, self.select_sets, C * D, device=self.device, dtype=dtype)
         self.temp = self._temp_v.view(bs, kv, self.select_sets, C * D)
         self.output = torch.zeros(bs, kv, self.sparse_budget, D, device=self.device, dtype=dtype)
         self._staged_layer = -1
@@ -248,6 +249,15 @@ class ShadowKVCache_CPU:
         # slot, then misses by id" - the same SET; host code that only hands the ids back to get_value_cache / get_key_cache
         # (base.py:320-338) does not see the difference.  Off by default: the default reproduces the reference's order.
         self.inplace_methods = False
+        # The reference's OWN launch sequence across boundary B2: with this flag the four decode methods issue exactly the
+        # calls of kv_cache.py:983-1176 - `kernels.shadowkv`'s twelve-name API (shadowkv_amd.kernels.shadowkv) and
+        # tensor_op.batch_gather_gemm_rotary_pos_emb_cuda, torch.max / topk / gather between the first two - with the
+        # reference's argument marshalling.  It is what a maintainer gets by swapping only the native module under the
+        # reference's unmodified Python, and the form whose arguments are pinned call by call to a
+        # recording of the reference itself (tests/test_decode_trace.py, tests/golden/trace_*.json).  Off by default: the
+        # default methods reach the same cache bytes with fewer, fused launches.
+        self.reference_calls = False
+        self.gemm_o = self.softmax_o = self.norm = self.sum = None    # scratch of the reference's scoring call (:773-780)
         self._last_cos_sin = None
         self._pending_v = None           # (layer_idx, position_ids) of a deferred get_value_cache
         self._early_pub = None           # layer whose selection published an early-fetch list (consumed by fetch_kv)
@@ -461,6 +471,8 @@ class ShadowKVCache_CPU:
         Returns position_ids[layer_idx] (reordered in place: hits by old slot, then misses by id);
         self.offsets / self.cnts are the mover's inputs."""
         self.incoming_q_len = query_states.shape[-2]
+        if self.reference_calls:
+            return self._ref_get_retrieval_position_ids(layer_idx, query_states)
         self._flush_pending_v()              # (a deferred V fetch reads the offsets / cnts this call is about to rewrite)
         if self.inplace_methods:
             if not self.lazy_value_fetch or self.resident_sets != self.select_sets:
@@ -551,6 +563,8 @@ class ShadowKVCache_CPU:
         region (kv_cache.py:1059-1106).  Runs on the CURRENT stream (call it under copy_stream): lands the
         hit chunks staged by get_retrieval_position_ids and pulls the misses over PCIe with plain 16-B loads
         (49-56 GB/s measured, the DMA ceiling; tools/pcie_probe.hip)."""
+        if self.reference_calls:
+            return self._ref_get_value_cache(layer_idx, position_ids)
         if not self.inplace_methods:
             self._reference_layout_only("get_value_cache")
         lv = self._layer(layer_idx)
@@ -567,6 +581,8 @@ class ShadowKVCache_CPU:
     def get_key_cache(self, layer_idx, position_ids, rope_func, cos_sin_cache):
         """Hit chunks moved to their new slots, miss chunks rebuilt as RoPE(U[idx].SV) straight into the sparse
         region (kv_cache.py:1108-1176), one launch.  `rope_func` is unused, as in the reference."""
+        if self.reference_calls:
+            return self._ref_get_key_cache(layer_idx, position_ids, cos_sin_cache)
         if not self.inplace_methods:
             self._reference_layout_only("get_key_cache")
         lv = self._layer(layer_idx)
@@ -585,6 +601,64 @@ class ShadowKVCache_CPU:
         tensor_op.rebuild_keys(lv.U, lv.SV, cos_sin_cache, position_ids, self.cnts, kbuf,
                                self.sparse_start, self.chunk_size, hit_temp=self._temp_k, hit_offsets=self.offsets)
         return kbuf[:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+
+    # ------------------------------------------------------------------ decode, the reference's own launch sequence
+    def _ref_scratch(self, n):
+        """gemm_o / softmax_o [bs, kv, G, n] bf16 and norm / sum [bs * kv, G, ceil(n / 256)] f32, zero-initialised: the scratch
+        the reference allocates in register_k_landmark (kv_cache.py:773-780) and moves in H2D (:1211-1214)."""
+        if self.gemm_o is None or self.gemm_o.shape[-1] != n:
+            bs, kv, G = self.batch_size, self.num_key_value_heads, self.num_key_value_groups
+            self.gemm_o = torch.zeros(bs, kv, G, n, device=self.device, dtype=self.dtype)
+            self.softmax_o = torch.zeros(bs, kv, G, n, device=self.device, dtype=self.dtype)
+            self.norm = torch.zeros(bs * kv, G, (n + 255) // 256, device=self.device, dtype=torch.float32)
+            self.sum = torch.zeros(bs * kv, G, (n + 255) // 256, device=self.device, dtype=torch.float32)
+
+    def _ref_guard(self, what):
+        if self.resident_sets != self.select_sets or self.inplace_methods or self.lazy_value_fetch:
+            raise RuntimeError(f"{what}: reference_calls reproduces the reference's launch sequence, which has neither a larger "
+                               "resident set nor the in-place / deferred variants")
+
+    def _ref_get_retrieval_position_ids(self, layer_idx, query_states):
+        """kv_cache.py:983-1057, call for call."""
+        self._ref_guard("get_retrieval_position_ids")
+        bs, kv, G = self.batch_size, self.num_key_value_heads, self.num_key_value_groups
+        lm = self.k_landmark[layer_idx]
+        self._ref_scratch(lm.shape[-2])
+        self.cnts = self._cnts_layers[0]          # ONE counts tensor shared by all layers, as in the reference (:629)
+        shadowkv.batch_gemm_softmax(query_states.contiguous(), lm.contiguous(), self.gemm_o, self.norm, self.sum,
+                                    self.softmax_o, bs * kv, G * self.incoming_q_len, lm.shape[-2], self.head_dim,
+                                    1 / math.sqrt(128), 0)
+        chunk_attn = self.softmax_o
+        if G > 1:
+            chunk_attn, _ = torch.max(self.softmax_o.view(bs, kv, G, -1), dim=-2)
+        top = torch.topk(chunk_attn.view(bs, kv, -1), k=self.select_sets, dim=-1).indices
+        selected_chunks = self.k_landmark_idx[layer_idx].gather(dim=-1, index=top)
+        shadowkv.reorder_keys_and_compute_offsets(self.position_ids[layer_idx], selected_chunks, self.offsets, self.cnts,
+                                                  bs, kv, self.select_sets)
+        return self.position_ids[layer_idx]
+
+    def _ref_get_value_cache(self, layer_idx, position_ids):
+        """kv_cache.py:1059-1106.  cpu_v_length: the reference passes max_ctx_chunks_len * head_dim, which IS the per-head
+        stride of its V table exactly when the table was sized for this prompt (max_length // chunk_size chunks); the stride
+        itself is passed here - the same number in every configuration the reference addresses correctly."""
+        self._ref_guard("get_value_cache")
+        vhost = self.v_cache_cpu[layer_idx]
+        shadowkv.gather_copy_with_offsets(vhost, self.v_cache_buffer[layer_idx], self.temp, self.offsets, self.cnts,
+                                          self.signals, self.batch_size, self.num_key_value_heads, int(vhost.stride(1)),
+                                          int(self.sparse_budget * self.head_dim), self.kernel_offset, self.kernel_stride,
+                                          self.select_sets)
+        return self.v_cache_buffer[layer_idx][:, :, :self.sparse_end + self._gen_rows(layer_idx)]
+
+    def _ref_get_key_cache(self, layer_idx, position_ids, cos_sin_cache):
+        """kv_cache.py:1108-1176: the d2d compaction of the hits, then the two-launch rebuild (tensor_op.py:201-238)."""
+        self._ref_guard("get_key_cache")
+        shadowkv.gather_copy_d2d_with_offsets(self.k_cache_buffer[layer_idx], self.offsets, self.cnts, self.batch_size,
+                                              self.num_key_value_heads, int(self.sparse_budget * self.head_dim),
+                                              self.kernel_offset, self.kernel_stride, self.select_sets)
+        tensor_op.batch_gather_gemm_rotary_pos_emb_cuda(self.U[layer_idx], self.SV[layer_idx], cos_sin_cache, position_ids,
+                                                        self.output, self.chunk_size, self.k_cache_buffer[layer_idx],
+                                                        self.sparse_start, self.sparse_end, self.cnts)
+        return self.k_cache_buffer[layer_idx][:, :, :self.sparse_end + self._gen_rows(layer_idx)]
 
     def _flush_pending_v(self):
         """A get_value_cache deferred by lazy_value_fetch that was not followed by the same layer's get_key_cache: its V
@@ -774,7 +848,7 @@ class ShadowKVCache_CPU:
             check(L.skv_early_state_set_landmark_map(ptr(states[l]), ptr(self.k_landmark_idx[l]), self.block_num,
                                                      self.num_key_value_groups, n_lm, n_chunks, E, st), "early_state_set_landmark_map")
         offs = (ctypes.c_longlong * 10)()
-        check(L.skv_early_state_offsets(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs), "early_state_offsets")
+        check(L.skv_early_state_offsets2(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs, 10), "early_state_offsets")
         torch.cuda.synchronize(self.device)
         if self._early is not None:
             self._early_retired = getattr(self, "_early_retired", []) + [self._early]

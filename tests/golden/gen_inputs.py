@@ -21,8 +21,26 @@ CASES = {
 }
 
 
+# ---- decode traces of the offload class (tests/golden/trace_*.json): 2 layers, the reference's ShadowKVCache_CPU driven
+# through its four decode methods.  trace_llama_b2048 has the headline's row layout (48 outlier chunks, prefill_local 64,
+# sparse region [448, 2496), 96 rows for generated tokens: SURVEY.md section 8) at a length torch.svd finishes in seconds.
+TRACE_CASES = {
+    "trace_llama_b1024": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=2200, budget=1024,
+                              chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9101),
+    "trace_llama_b2048": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=8256, budget=2048,
+                              chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9202),
+    "trace_glm_small": dict(layers=2, q_heads=32, kv_heads=4, head_dim=128, L=2048, budget=256,
+                            chunk=8, rank=160, rope_theta=10000.0, glm=True, seed=9303),
+}
+TRACE_STEPS = 4
+
+
+def case_of(case):
+    return CASES[case] if case in CASES else TRACE_CASES[case]
+
+
 def config_of(case):
-    c = CASES[case]
+    c = case_of(case)
     return SimpleNamespace(num_hidden_layers=c["layers"], num_attention_heads=c["q_heads"],
                            num_key_value_heads=c["kv_heads"], hidden_size=c["q_heads"] * c["head_dim"])
 
@@ -30,7 +48,7 @@ def config_of(case):
 def cos_sin_cache(case, max_pos):
     """Llama: [max_pos, 128] = cos[:64] | sin[:64] (models/llama.py:323-332 layout).
     GLM: [max_pos, 64] = cos[:32] | sin[:32] (models/glm.py:261-273 layout)."""
-    c = CASES[case]
+    c = case_of(case)
     rot = 64 if c["glm"] else c["head_dim"]
     inv_freq = 1.0 / (c["rope_theta"] ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
     t = torch.arange(max_pos, dtype=torch.float32)
@@ -38,11 +56,11 @@ def cos_sin_cache(case, max_pos):
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.bfloat16).contiguous()
 
 
-def make_inputs(case):
+def make_inputs(case, layer=0):
     """Returns dict(k_pre [1,kv,L,D] bf16 pre-RoPE (approximately rank-`rank`), v [1,kv,L,D],
-    q_last [1,q_heads,1,D], q_steps [steps,1,q_heads,1,D], cos_sin)."""
-    c = CASES[case]
-    g = torch.Generator().manual_seed(c["seed"])
+    q_last [1,q_heads,1,D], q_steps [steps,1,q_heads,1,D], cos_sin).  layer > 0: another draw (trace cases)."""
+    c = case_of(case)
+    g = torch.Generator().manual_seed(c["seed"] + 1000 * layer)
     L, kv, D, r = c["L"], c["kv_heads"], c["head_dim"], c["rank"]
     a = torch.randn(L, r, generator=g)
     b = torch.randn(r, kv * D, generator=g) / math.sqrt(r)
@@ -92,7 +110,33 @@ def rope_glm_torch(x, cos_sin, position_ids):
 
 
 def rope_torch(case, x, cos_sin, position_ids):
-    return rope_glm_torch(x, cos_sin, position_ids) if CASES[case]["glm"] else rope_neox_torch(x, cos_sin, position_ids)
+    return rope_glm_torch(x, cos_sin, position_ids) if case_of(case)["glm"] else rope_neox_torch(x, cos_sin, position_ids)
+
+
+def trace_new_token(case, step, layer):
+    """The decoded token's K (as handed to update_kv_cache: post-RoPE, any bf16 values will do) and V, [1, kv, 1, D]."""
+    c = TRACE_CASES[case]
+    g = torch.Generator().manual_seed(c["seed"] * 31 + step * 17 + layer * 5 + 1)
+    k = torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16)
+    v = torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16)
+    return k, v
+
+
+def trace_query_draw(case, q_prev, step, layer, attempt):
+    """Random-walk query of (step, layer), draw number `attempt`: [1, q_heads, 1, D] bf16 from the previous accepted one."""
+    c = TRACE_CASES[case]
+    g = torch.Generator().manual_seed(((c["seed"] * 131 + step) * 31 + layer) * 4099 + attempt)
+    return (q_prev.float() + 0.5 * torch.randn(q_prev.shape, generator=g)).to(torch.bfloat16)
+
+
+def trace_query(case, q_prev, step, layer, attempts):
+    """The query of (step, layer): the q heads of KV group h come from draw number attempts[h].  The fixture generator takes,
+    per KV head, the first draw whose top-k boundary is unique (any correct top-k then returns the same SET - the reference
+    leaves membership under ties undefined) and stores the numbers; the groups are independent."""
+    c = TRACE_CASES[case]
+    kv, groups = c["kv_heads"], c["q_heads"] // c["kv_heads"]
+    draws = {a: trace_query_draw(case, q_prev, step, layer, a) for a in set(attempts)}
+    return torch.cat([draws[attempts[h]][:, h * groups:(h + 1) * groups] for h in range(kv)], dim=1).contiguous()
 
 
 # ---- selection stage at the headline size (tests/golden/select_122k.npz) ------------------------------------

@@ -36,6 +36,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))        # repo root: `import oracle` (trace stand-in's back end)
 import gen_inputs as G  # noqa: E402
 
 REF = "/root/reference/models/kv_cache.py"
@@ -199,7 +200,95 @@ def run_select_122k(ref):
             "meta": np.array([cache.chunks, cache.select_sets, cache.outlier_chunk, lm_idx.shape[-1]], dtype=np.int64)}
 
 
+def load_reference_offload(kernels_shadowkv):
+    """The reference's models/kv_cache.py AND its models/tensor_op.py, loaded in place, with `kernels.shadowkv` = the given
+    module (tests/golden/trace_standin.py: records + carries the calls out through oracle/).  tensor_op.py imports
+    flashinfer / minference (absent; none of their names is used on the decode path of the cache: empty placeholders) and
+    builds one mask on "cuda" at import time (tensor_op.py:55-57; device dropped for the duration of the import).  What runs
+    afterwards - ShadowKVCache_CPU's methods and tensor_op.batch_gather_gemm_rotary_pos_emb_cuda /
+    apply_rotary_pos_emb_cuda_push_cache (tensor_op.py:171-238) - is the reference's own code, unmodified."""
+    load_reference_kv_cache()                      # (torch.cuda / pin_memory no-ops)
+    saved = {n: sys.modules.get(n) for n in ("models", "models.tensor_op", "kernels", "kernels.shadowkv", "flashinfer",
+                                             "flashinfer.norm", "minference")}
+    for name in ("models", "kernels", "flashinfer", "flashinfer.norm", "minference"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["kernels.shadowkv"] = kernels_shadowkv
+    sys.modules["kernels"].shadowkv = kernels_shadowkv
+    sys.modules["flashinfer.norm"].rmsnorm = None
+    for n in ("vertical_slash_sparse_attention", "block_sparse_attention", "streaming_forward"):
+        setattr(sys.modules["minference"], n, None)
+    _arange = torch.arange
+
+    def arange_nodev(*a, **k):
+        k.pop("device", None)
+        return _arange(*a, **k)
+
+    try:
+        torch.arange = arange_nodev
+        spec = importlib.util.spec_from_file_location("models.tensor_op", "/root/reference/models/tensor_op.py")
+        top = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(top)
+    finally:
+        torch.arange = _arange
+    sys.modules["models.tensor_op"] = top
+    spec = importlib.util.spec_from_file_location("ref_kv_cache_offload", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.batch_gather_gemm_rotary_pos_emb_cuda is top.batch_gather_gemm_rotary_pos_emb_cuda
+    assert mod.shadowkv is kernels_shadowkv and top.shadowkv is kernels_shadowkv
+    for n, m in saved.items():
+        if m is None:
+            sys.modules.pop(n, None)
+        else:
+            sys.modules[n] = m
+    return mod
+
+
+def run_trace(case):
+    """Decode half of the reference's ShadowKVCache_CPU (models/kv_cache.py:983-1176, 1227-1271): 2 layers x TRACE_STEPS
+    steps in layer_compute's order, every call across `kernels.shadowkv` recorded (trace_standin.KernelTrace), state
+    snapshots after every (step, layer)."""
+    import trace_driver as TD
+    from trace_standin import KernelTrace, digest as digest128
+    c = G.TRACE_CASES[case]
+    trace = KernelTrace()
+    ref = load_reference_offload(trace.module())
+    cache = ref.ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                                  sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    inputs = TD.layer_inputs(case)
+    TD.prefill(cache, case, inputs)
+    assert not trace.calls, "prefill crossed the native boundary"
+    meta = {"chunks": cache.chunks, "prefill_local": cache.prefill_local, "sparse_start": cache.sparse_start,
+            "sparse_end": cache.sparse_end, "select_sets": cache.select_sets, "outlier_chunk": cache.outlier_chunk,
+            "max_ctx_chunks_len": cache.max_ctx_chunks_len, "kernel_offset": cache.kernel_offset,
+            "kernel_stride": cache.kernel_stride, "kv_offset": cache.kv_offset, "gen_offset": cache.gen_offset,
+            "buffer_rows": cache.k_cache_buffer.shape[-2], "landmarks": cache.k_landmark.shape[-2]}
+    state0 = {"U": digest128(cache.U), "SV": digest128(cache.SV), "k_landmark": digest128(cache.k_landmark),
+              "k_landmark_idx": digest128(cache.k_landmark_idx), "position_ids": digest128(cache.position_ids),
+              "k_cache_buffer": digest128(cache.k_cache_buffer), "v_cache_buffer": digest128(cache.v_cache_buffer),
+              "v_cache_cpu": digest128(cache.v_cache_cpu)}
+    snaps, tries, qd = TD.decode(cache, case, inputs, trace=trace)
+    hits = [[sum(s["cnts"]) / (len(s["cnts"]) * cache.select_sets) for s in row] for row in snaps]
+    return {"case": case, "meta": meta, "state_after_prefill": state0, "q_try": tries, "q_digest": qd,
+            "chunk_hit_rate": hits, "snapshots": snaps, "calls": trace.calls}
+
+
+def write_trace(case):
+    import json
+    out = run_trace(case)
+    path = os.path.join(HERE, f"{case}.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
+    print(case, len(out["calls"]), "calls; q_try", out["q_try"], "hit rate",
+          [[round(x, 2) for x in r] for r in out["chunk_hit_rate"]], os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
+    if "--only-traces" in sys.argv:
+        for case in G.TRACE_CASES:
+            write_trace(case)
+        return
     ref = load_reference_kv_cache()
     if "--only-small" not in sys.argv:
         out = run_select_122k(ref)
@@ -211,6 +300,8 @@ def main():
         path = os.path.join(HERE, f"{case}.npz")
         np.savez_compressed(path, **out)
         print(case, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
+    for case in G.TRACE_CASES:
+        write_trace(case)
 
 
 if __name__ == "__main__":

@@ -713,7 +713,10 @@ def test_early_fetch_landmark_map_reproduces_the_slot_to_chunk_ids():
     state = torch.empty(L_.skv_early_state_bytes(B, G, N, n_chunks, E), dtype=torch.uint8, device=DEV)
     _lib.check(L_.skv_early_state_init(state.data_ptr(), B, G, N, n_chunks, E, 0), "early_state_init")
     offs = (ctypes.c_longlong * 10)()
-    _lib.check(L_.skv_early_state_offsets(B, G, N, n_chunks, E, offs), "early_state_offsets")
+    _lib.check(L_.skv_early_state_offsets2(B, G, N, n_chunks, E, offs, 10), "early_state_offsets2")
+    off8 = (ctypes.c_longlong * 9)(*([-7] * 9))                 # the round-3 name keeps its eight-entry contract
+    _lib.check(L_.skv_early_state_offsets(B, G, N, n_chunks, E, ctypes.cast(off8, ctypes.POINTER(ctypes.c_longlong))), "early_state_offsets")
+    assert list(off8)[:8] == list(offs)[:8] and off8[8] == -7
     good = torch.arange(N, dtype=torch.int64) + (torch.arange(N) >= 500) * 3
     bad = good.clone(); bad[10], bad[11] = good[11], good[10]
     lm = torch.stack([good, bad]).to(DEV)
@@ -721,3 +724,26 @@ def test_early_fetch_landmark_map_reproduces_the_slot_to_chunk_ids():
     torch.cuda.synchronize()
     assert state[offs[9]:offs[9] + 8].view(torch.int32).cpu().tolist() == [1, 0]
     assert state[offs[8]:offs[8] + 12].view(torch.int32).cpu().tolist() == [500, 500, 500]
+    # ids BELOW their slot index (d_j - of the previous slot - negative while d_j itself is in range) on head 0 AND
+    # head 1: flagged, and no byte in front of / outside a head's own gap table is written (head 0's table is preceded by
+    # the staging, early_of and early_ids regions; head 1's by head 0's table)
+    for kind in ("zeros", "duplicates", "one_low"):
+        _lib.check(L_.skv_early_state_init(state.data_ptr(), B, G, N, n_chunks, E, 0), "early_state_init")
+        low = good.clone()
+        if kind == "zeros":
+            low[200:260] = 0                                       # d = -j over a run, then back in range at slot 260
+        elif kind == "duplicates":
+            low[1:] = good[:-1].clone(); low[300:] = good[300]     # one id repeated to the end: d falls below zero
+        else:
+            low[700] = 5                                           # a single id far below its slot; slot 701 has dp = -695, d = 3
+        lm = torch.stack([low, low]).to(DEV)
+        torch.cuda.synchronize()
+        before = state.clone()
+        _lib.check(L_.skv_early_state_set_landmark_map(state.data_ptr(), lm.data_ptr(), B, G, N, n_chunks, E, 0), "set_landmark_map")
+        torch.cuda.synchronize()
+        assert state[offs[9]:offs[9] + 8].view(torch.int32).cpu().tolist() == [0, 0], kind
+        lo, hi = offs[8], offs[8] + 4 * B * 128                   # the gap tables
+        assert torch.equal(state[:lo], before[:lo]), f"{kind}: bytes in front of the gap tables changed"
+        rest = torch.ones(state.numel() - hi, dtype=torch.bool, device=DEV)
+        rest[offs[9] - hi:offs[9] - hi + 4 * B] = False            # (map_ok itself is written)
+        assert torch.equal(state[hi:][rest], before[hi:][rest]), f"{kind}: bytes behind the gap tables changed"
