@@ -62,6 +62,28 @@ def set_num_threads(n):
     lib().oracle_set_num_threads(_i(int(n)))
 
 
+def bind_threads(cpus, whole_set=False):
+    """Binds OpenMP thread t of the current team to cpus[t % len(cpus)] (see oracle_bind_threads; thread 0 is the caller);
+    whole_set: every thread may run on all of `cpus` again."""
+    arr = (ctypes.c_int * len(cpus))(*cpus)
+    return int(lib().oracle_bind_threads(arr, len(cpus), _i(1 if whole_set else 0)))
+
+
+def thread_cpus():
+    out = (ctypes.c_int * 1024)(*([-1] * 1024))
+    n = int(lib().oracle_thread_cpus(out, 1024))
+    return list(out)[:n]
+
+
+def first_touch_clone(t):
+    """A copy of CPU tensor t whose pages are first written by the OpenMP threads (static partition) instead of the caller."""
+    assert t.device.type == "cpu" and t.is_contiguous()
+    out = torch.empty_like(t)
+    lib().oracle_parallel_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib().oracle_parallel_copy(out.data_ptr(), t.data_ptr(), t.numel() * t.element_size())
+    return out
+
+
 def group_max_topk(P, landmark_idx, blocks, groups, n, topk):
     """P bf16 [blocks, groups, n] -> int64 [blocks, topk] (ascending slot order)."""
     out = torch.empty(blocks, topk, dtype=torch.int64)

@@ -21,8 +21,10 @@
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp)
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <omp.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -447,6 +449,51 @@ ORACLE_API void oracle_batch_gather_gemm(const uint16_t *U, const uint16_t *SV,
 /* threads the parallel loops above run on (bench.py reports it with the cpu_baseline) */
 ORACLE_API int oracle_num_threads(void) { return omp_get_max_threads(); }
 ORACLE_API void oracle_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
+/* cpu_baseline hygiene (bench.py): bind OpenMP thread t of the current team size to cpus[t % n_cpus] (one logical CPU per
+ * physical core, chosen by the caller).  The OpenMP runtime is shared with torch and was initialised before any OMP_PROC_BIND
+ * could be set for it, so the binding is done here, per thread, after the team size is chosen.  Thread 0 is the CALLING
+ * thread: the caller restores its affinity afterwards (whole_set = 1 gives every thread of the team the whole list back).
+ * Returns the number of threads bound. */
+ORACLE_API int oracle_bind_threads(const int *cpus, int n_cpus, int whole_set) {
+    int bound = 0;
+    if (!cpus || n_cpus < 1) return 0;
+#pragma omp parallel reduction(+ : bound)
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (whole_set)              /* undo: every thread may run on every listed CPU again */
+            for (int i = 0; i < n_cpus; ++i) CPU_SET(cpus[i], &set);
+        else
+            CPU_SET(cpus[omp_get_thread_num() % n_cpus], &set);
+        if (sched_setaffinity(0, sizeof(set), &set) == 0) bound += 1;
+    }
+    return bound;
+}
+
+/* the CPU every OpenMP thread of the current team runs on right now (diagnostic of the binding above) */
+ORACLE_API int oracle_thread_cpus(int *out, int n_out) {
+    int n = 0;
+#pragma omp parallel
+    {
+        const int t = omp_get_thread_num();
+        if (t < n_out) out[t] = sched_getcpu();
+#pragma omp single
+        n = omp_get_num_threads();
+    }
+    return n;
+}
+
+/* first touch: copy n bytes with the static partition the scoring / gather loops use over contiguous per-head state, so a page
+ * of `dst` lands on the NUMA node of a thread that will read it */
+ORACLE_API void oracle_parallel_copy(void *dst, const void *src, size_t n) {
+    const size_t page = 4096, pages = (n + page - 1) / page;
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < pages; ++p) {
+        const size_t o = p * page, len = o + page <= n ? page : n - o;
+        memcpy((char *)dst + o, (const char *)src + o, len);
+    }
+}
 
 /* ------------------------------------------------------------------------- */
 /* a8: RoPE and push into the key cache (kernels/rope_new.cu)                */

@@ -265,6 +265,7 @@ class ShadowKVCache_CPU:
         # measurement hook (bench.py): a list -> every fetch launch of the in-place path is bracketed by two events on the
         # current stream and (start, end, layer) is appended; None (default): nothing is recorded
         self.fetch_events = None
+        self.attn_out_tap = None         # test hook: see select_fetch_attend_inplace
         self._copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -940,7 +941,10 @@ class ShadowKVCache_CPU:
         else:
             check(L.skv_fetch_kv_attn_inplace(*fetch_args, st), "fetch_kv_attn_inplace")
         self._fetch_event(ev0, layer_idx)
-        out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device)
+        # (attn_out_tap: a list of per-layer [bs, 1, Hq, D] tensors a test hands in to keep every layer's attention output of
+        # a captured step - the merge launch then writes there instead of into a fresh tensor; no extra launch)
+        tap = self.attn_out_tap
+        out = torch.empty(bs, 1, Hq, D, dtype=q.dtype, device=q.device) if tap is None else tap[layer_idx]
         check(L.skv_attn_finish_inplace(ptr(ws), ptr(self.cnts), ptr(out), bs, Hq, self.num_key_value_heads,
                                         self.select_sets, SA, st), "attn_finish_inplace")
         return out

@@ -35,8 +35,35 @@ TRACE_CASES = {
 TRACE_STEPS = 4
 
 
+# ---- sub-batched prefill (tests/golden/subbatch_prefill.json): LLM.batch_prefill (models/base.py:500-548) prefills a batch
+# in sub-batches of T sequences, every layer per sub-batch; the cache keeps `prefilled_batch` (kv_cache.py:683-737, 788-980).
+SUBBATCH_CASES = {
+    "subbatch_llama": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=2048, budget=256, chunk=8, rank=160,
+                           rope_theta=500000.0, glm=False, seed=9404, batch=4, sub=2),
+}
+
+
 def case_of(case):
-    return CASES[case] if case in CASES else TRACE_CASES[case]
+    for d in (CASES, TRACE_CASES, SUBBATCH_CASES):
+        if case in d:
+            return d[case]
+    raise KeyError(case)
+
+
+def subbatch_inputs(case):
+    """Per layer: k_pre [B, L, kv*D] (the [bsz, seq, hidden] layout of get_svd, kv_cache.py:683), k_roped / v [B, kv, L, D],
+    q_last [B, Hq, 1, D] - sequence b of layer l is make_inputs(case, layer=8 * l + b)."""
+    c = SUBBATCH_CASES[case]
+    out = []
+    for l in range(c["layers"]):
+        per = [make_inputs(case, layer=8 * l + b) for b in range(c["batch"])]
+        pos = torch.arange(c["L"]).unsqueeze(0)
+        k4 = torch.cat([p["k_pre"] for p in per])                                   # [B, kv, L, D]
+        out.append(dict(k_pre=k4.transpose(1, 2).reshape(c["batch"], c["L"], -1).contiguous(),
+                        k_roped=torch.cat([rope_torch(case, p["k_pre"], p["cos_sin"], pos) for p in per]),
+                        v=torch.cat([p["v"] for p in per]), q_last=torch.cat([p["q_last"] for p in per]),
+                        cos_sin=per[0]["cos_sin"]))
+    return out
 
 
 def config_of(case):

@@ -244,6 +244,9 @@ def load_reference_offload(kernels_shadowkv):
     return mod
 
 
+TRACE_FACTOR_CASES = ("trace_llama_b1024", "trace_glm_small")      # (trace_llama_b2048's U alone is 5.3 MB: not shipped)
+
+
 def run_trace(case):
     """Decode half of the reference's ShadowKVCache_CPU (models/kv_cache.py:983-1176, 1227-1271): 2 layers x TRACE_STEPS
     steps in layer_compute's order, every call across `kernels.shadowkv` recorded (trace_standin.KernelTrace), state
@@ -267,10 +270,50 @@ def run_trace(case):
               "k_landmark_idx": digest128(cache.k_landmark_idx), "position_ids": digest128(cache.position_ids),
               "k_cache_buffer": digest128(cache.k_cache_buffer), "v_cache_buffer": digest128(cache.v_cache_buffer),
               "v_cache_cpu": digest128(cache.v_cache_cpu)}
+    if case in TRACE_FACTOR_CASES:
+        # the reference's SVD factors themselves (bf16 as uint16): torch.svd goes through LAPACK, whose low-order bits depend on
+        # the CPU model - a GPU box cannot regenerate them, and with them the recording's K bytes are reproducible anywhere
+        np.savez_compressed(os.path.join(HERE, f"{case}_factors.npz"), U=u16(cache.U), SV=u16(cache.SV))
     snaps, tries, qd = TD.decode(cache, case, inputs, trace=trace)
     hits = [[sum(s["cnts"]) / (len(s["cnts"]) * cache.select_sets) for s in row] for row in snaps]
     return {"case": case, "meta": meta, "state_after_prefill": state0, "q_try": tries, "q_digest": qd,
             "chunk_hit_rate": hits, "snapshots": snaps, "calls": trace.calls}
+
+
+STATE_NAMES = ("U", "SV", "k_landmark", "k_landmark_idx", "position_ids", "k_cache_buffer", "v_cache_buffer", "v_cache_cpu")
+
+
+def run_subbatch(case):
+    """The reference's ShadowKVCache_CPU prefilled the way LLM.batch_prefill does it (models/base.py:533-543): sub-batches of
+    `sub` sequences, every layer per sub-batch (get_svd, prefill_kv_cache: kv_cache.py:683-737, 788-980)."""
+    from trace_standin import digest as digest128
+    c = G.SUBBATCH_CASES[case]
+    ref = load_reference_kv_cache()
+    cache = ref.ShadowKVCache_CPU(G.config_of(case), batch_size=c["batch"], max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                                  sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    inputs = G.subbatch_inputs(case)
+    progress = []
+    for b0 in range(0, c["batch"], c["sub"]):
+        sl = slice(b0, b0 + c["sub"])
+        for l, inp in enumerate(inputs):
+            cache.get_svd(inp["k_pre"][sl], l)
+            cache.prefill_kv_cache(inp["v"][sl], l, inp["k_roped"][sl], inp["q_last"][sl])
+        progress.append({"prefilled_batch": cache.prefilled_batch, "kv_offset": cache.kv_offset, "kv_len": cache.get_kv_len()})
+    cache.H2D()
+    return {"case": case, "progress": progress, "state": {n: digest128(getattr(cache, n)) for n in STATE_NAMES},
+            "per_sequence": [{n: digest128(getattr(cache, n)[:, b:b + 1]) for n in STATE_NAMES} for b in range(c["batch"])],
+            "meta": {"chunks": cache.chunks, "prefill_local": cache.prefill_local, "sparse_start": cache.sparse_start,
+                     "sparse_end": cache.sparse_end, "landmarks": cache.k_landmark.shape[-2]}}
+
+
+def write_subbatch(case):
+    import json
+    out = run_subbatch(case)
+    path = os.path.join(HERE, "subbatch_prefill.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
+    print(case, out["progress"], os.path.getsize(path), "B")
 
 
 def write_trace(case):
@@ -288,6 +331,8 @@ def main():
     if "--only-traces" in sys.argv:
         for case in G.TRACE_CASES:
             write_trace(case)
+        for case in G.SUBBATCH_CASES:
+            write_subbatch(case)
         return
     ref = load_reference_kv_cache()
     if "--only-small" not in sys.argv:
@@ -302,6 +347,8 @@ def main():
         print(case, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
     for case in G.TRACE_CASES:
         write_trace(case)
+    for case in G.SUBBATCH_CASES:
+        write_subbatch(case)
 
 
 if __name__ == "__main__":

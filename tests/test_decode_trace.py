@@ -94,6 +94,18 @@ def test_decode_calls_and_state_equal_the_reference_recording(case, monkeypatch)
     assert all(0.0 < x < 1.0 for row in z["chunk_hit_rate"] for x in row)      # every step mixes hits and misses
 
 
+@pytest.mark.parametrize("case", ["trace_llama_b1024", "trace_glm_small"])
+def test_shipped_factors_are_the_recordings(case):
+    """tests/golden/<case>_factors.npz (the reference's U / SV, for GPU boxes whose LAPACK rounds differently): the digests the
+    recording holds."""
+    import numpy as np
+    z = load_fixture(case)
+    f = np.load(os.path.join(GOLD, f"{case}_factors.npz"))
+    for n in ("U", "SV"):
+        t = torch.from_numpy(f[n].astype(np.int16)).view(torch.bfloat16)
+        assert digest(t) == z["state_after_prefill"][n]
+
+
 def test_headline_row_layout_case_has_48_outliers():
     m = load_fixture("trace_llama_b2048")["meta"]
     assert (m["outlier_chunk"], m["prefill_local"], m["sparse_start"], m["sparse_end"], m["buffer_rows"],

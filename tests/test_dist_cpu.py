@@ -173,12 +173,64 @@ def test_bench_main_on_two_ranks_prints_one_line_on_rank_zero():
         assert key not in rec
 
 
-def test_bench_main_refuses_gpus_without_a_launcher():
+def _plain_bench(extra_env=None, args=("--gpus", "2", "--steps", "10", "--warmup", "2")):
+    """`bench.main([...])` in a fresh interpreter with NO launcher variables: the parent must start its own replicas."""
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; "
+            "bench.CHILD_ENTRY = [sys.executable, os.path.join(%r, 'tests', '_bench_stub_child.py')]; "
+            "import torch; bench.main(%r); "
+            "assert not torch.cuda.is_initialized()" % (ROOT, ROOT, list(args)))
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_plain_bench_gpus_2_launches_its_own_replicas():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it.  The parent starts two ranks (gloo
+    and the stub seams here), relays rank 0's single JSON line and exits 0 - without initialising the GPU runtime itself."""
+    import json
+    r = _plain_bench()
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 10 and rec["scaling"] == "weak"
+    assert [x["rank"] for x in rec["per_rank"]] == [0, 1]
+    assert rec["value"] == 2 * 10 / 1.0
+
+
+def test_plain_bench_returns_the_worst_child_exit_code():
+    """A rank that dies must not leave the other waiting in a barrier: the launcher stops it and reports the failure."""
+    r = _plain_bench({"SKV_TEST_FAIL_RANK": "1"})
+    assert r.returncode == 7 and r.stdout.strip() == "" and "rank 1 exited with code 7" in r.stderr
+
+
+def test_launcher_form_with_a_wrong_world_size_is_refused():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=120)
-    assert r.returncode == 2 and r.stdout.strip() == "" and "torch.distributed.run --nproc-per-node 2" in r.stderr
+    assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE is 1" in r.stderr
+
+
+def test_gpu_numa_cpulists_from_the_kfd_topology(tmp_path):
+    """The launcher reads each GPU's NUMA CPU list from sysfs (KFD topology -> PCI address -> numa_node) without a HIP call."""
+    import bench
+    root = tmp_path
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    spec = {0: (0, 0, 0), 1: (0, 0, 0), 2: (256, 0x0500, 0), 3: (256, 0x1500 | (0 << 3), 1)}      # two CPU nodes, two GPUs
+    for n, (simd, loc, dom) in spec.items():
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\nlocation_id {loc}\ndomain {dom}\n")
+    for bdf, node in (("0000:05:00.0", 1), ("0001:15:00.0", 0)):
+        (root / "bus/pci/devices" / bdf).mkdir(parents=True)
+        (root / "bus/pci/devices" / bdf / "numa_node").write_text(f"{node}\n")
+    for node, lst in ((0, "0-31,64-95"), (1, "32-63,96-127")):
+        (root / f"devices/system/node/node{node}").mkdir(parents=True)
+        (root / f"devices/system/node/node{node}/cpulist").write_text(lst + "\n")
+    assert bench.gpu_numa_cpus_from_sysfs(2, str(root)) == ["32-63,96-127", "0-31,64-95"]
+    assert bench.gpu_numa_cpus_from_sysfs(3, str(root)) == ["32-63,96-127", "0-31,64-95", None]
+    assert bench.gpu_numa_cpus_from_sysfs(2, str(tmp_path / "missing")) == [None, None]
 
 
 def test_process_numa_node_falls_back_to_the_node_cpulists(tmp_path):
@@ -202,3 +254,52 @@ def test_process_numa_node_falls_back_to_the_node_cpulists(tmp_path):
     assert bench.process_numa_node(str(bare)) == 0
     assert bench.process_numa_node(str(tmp_path / "missing")) is None
     assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def test_cgroup_cpu_quota_and_core_list(tmp_path):
+    """cpu_baseline's thread count: min(physical cores allowed, cgroup CPU quota) - VERDICT r4 #7."""
+    import bench
+    root = tmp_path / "cg"
+    (root / "pod" / "job").mkdir(parents=True)
+    (root / "cpu.max").write_text("max 100000\n")
+    (root / "pod" / "cpu.max").write_text("6400000 100000\n")
+    (root / "pod" / "job" / "cpu.max").write_text("3200000 100000\n")
+    proc = tmp_path / "cgroup"
+    proc.write_text("0::/pod/job\n")
+    assert bench.cgroup_cpu_quota(str(proc), str(root)) == 32.0                 # the tightest limit on the path
+    proc.write_text("0::/pod\n")
+    assert bench.cgroup_cpu_quota(str(proc), str(root)) == 64.0
+    proc.write_text("0::/\n")
+    assert bench.cgroup_cpu_quota(str(proc), str(root)) is None                 # "max": no limit
+    v1 = tmp_path / "v1"
+    (v1 / "cpu" / "docker").mkdir(parents=True)
+    (v1 / "cpu" / "docker" / "cpu.cfs_quota_us").write_text("1650000\n")
+    (v1 / "cpu" / "docker" / "cpu.cfs_period_us").write_text("100000\n")
+    proc.write_text("4:cpu,cpuacct:/docker\n")
+    assert bench.cgroup_cpu_quota(str(proc), str(v1)) == 16.5
+    assert bench.cgroup_cpu_quota(str(tmp_path / "none"), str(tmp_path / "none")) is None
+    cpus = tmp_path / "cpu"
+    for cpu, (pkg, core) in {0: (0, 0), 1: (0, 1), 2: (1, 0), 3: (1, 1), 4: (0, 0), 5: (0, 1), 6: (1, 0), 7: (1, 1)}.items():
+        (cpus / f"cpu{cpu}" / "topology").mkdir(parents=True)
+        (cpus / f"cpu{cpu}" / "topology" / "physical_package_id").write_text(f"{pkg}\n")
+        (cpus / f"cpu{cpu}" / "topology" / "core_id").write_text(f"{core}\n")
+    assert bench.one_cpu_per_core(range(8), str(cpus)) == [0, 1, 2, 3]           # SMT siblings 4..7 counted once
+    assert bench.one_cpu_per_core([1, 5, 6, 7], str(cpus)) == [1, 6, 7]
+    assert bench.one_cpu_per_core([3, 1], str(tmp_path / "missing")) == [1, 3]
+
+
+def test_oracle_thread_binding_round_trip():
+    import oracle
+    allowed = sorted(os.sched_getaffinity(0))
+    n = min(4, len(allowed))
+    before = oracle.num_threads()
+    try:
+        oracle.set_num_threads(n)
+        assert oracle.bind_threads(allowed[:n]) == n
+        assert sorted(oracle.thread_cpus()) == allowed[:n]                       # one thread per listed CPU
+        assert oracle.bind_threads(allowed, whole_set=True) == n
+    finally:
+        os.sched_setaffinity(0, allowed)
+        oracle.set_num_threads(before)
+    t = torch.arange(100000, dtype=torch.float32)
+    assert torch.equal(oracle.first_touch_clone(t), t)

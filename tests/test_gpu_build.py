@@ -206,3 +206,95 @@ def test_default_factorisation_on_a_gpu_is_the_gram_path():
     cpu.get_svd(inp["k_pre"], 0); ref.get_svd(inp["k_pre"], 0)
     assert_bits_equal(cpu.U, ref.U)
     assert_bits_equal(cpu.SV, ref.SV)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sub-batched prefill on the device (VERDICT r4 missing #4 / SURVEY 8f3): LLM.batch_prefill's pattern
+# (/root/reference/models/base.py:533-543; kv_cache.py:683-737, 788-980) - the CPU counterpart
+# (tests/test_kv_cache_cpu.py::test_subbatched_prefill_equals_the_reference_and_the_one_shot_build) pins it to the reference.
+# ---------------------------------------------------------------------------------------------------------------------
+def _device_prefill(case, sub, only=None, factor_on="cpu"):
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    c = G.SUBBATCH_CASES[case]
+    inputs = G.subbatch_inputs(case)
+    seqs = list(range(c["batch"])) if only is None else [only]
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=len(seqs), max_length=c["L"], device=DEV, dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    for i in range(0, len(seqs), sub):
+        idx = seqs[i:i + sub]
+        for l, inp in enumerate(inputs):
+            # factor_on="cpu": torch.svd through LAPACK, one matrix at a time whatever the batch - the factors do not depend on
+            # how the batch was cut (a batched rocSOLVER / hipBLASLt call may pick another algorithm per batch count)
+            k_pre = inp["k_pre"][idx]
+            cache.get_svd(k_pre if factor_on == "cpu" else k_pre.to(DEV), l)
+            cache.prefill_kv_cache(inp["v"][idx].to(DEV), l, inp["k_roped"][idx].to(DEV), inp["q_last"][idx].to(DEV))
+        assert cache.prefilled_batch == min(i + sub, len(seqs))
+        assert cache.kv_offset == (c["L"] if cache.prefilled_batch == len(seqs) else 0)
+    cache.H2D()
+    torch.cuda.synchronize()
+    return cache, inputs
+
+
+def _decode3(case, cache, inputs, seqs):
+    """3 decode steps x layers in the reference's method order; returns the per-step observable state."""
+    c = G.SUBBATCH_CASES[case]
+    cs = inputs[0]["cos_sin"].to(DEV)
+    out = []
+    q_prev = [inp["q_last"][seqs] for inp in inputs]
+    for t in range(3):
+        for l in range(c["layers"]):
+            g = torch.Generator().manual_seed(1000 * t + l)
+            noise = torch.randn(c["batch"], c["q_heads"], 1, c["head_dim"], generator=g)[seqs]
+            q = (q_prev[l].float() + 0.5 * noise).bfloat16()
+            q_prev[l] = q
+            kn = torch.randn(c["batch"], c["kv_heads"], 1, c["head_dim"], generator=g)[seqs].bfloat16()
+            vn = torch.randn(c["batch"], c["kv_heads"], 1, c["head_dim"], generator=g)[seqs].bfloat16()
+            cache.update_kv_cache(kn.to(DEV), vn.to(DEV), l)
+            pos = cache.get_retrieval_position_ids(layer_idx=l, query_states=q.to(DEV))
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(cache.copy_stream):
+                cache.copy_stream.wait_stream(cur)
+                v = cache.get_value_cache(l, pos)
+            k = cache.get_key_cache(layer_idx=l, position_ids=pos, rope_func=None, cos_sin_cache=cs)
+            cur.wait_stream(cache.copy_stream)
+            torch.cuda.synchronize()
+            out.append(dict(pos=pos.cpu().clone(), cnts=cache.cnts.cpu().clone().view(len(seqs), -1), k=k.cpu().clone(),
+                            v=v.cpu().clone()))
+    return out
+
+
+def test_subbatched_prefill_on_the_device_then_decode():
+    case = "subbatch_llama"
+    c = G.SUBBATCH_CASES[case]
+    B = c["batch"]
+    sub, inputs = _device_prefill(case, c["sub"])
+    one, _ = _device_prefill(case, B)
+    names = ("U", "SV", "k_landmark", "k_landmark_idx", "position_ids", "k_cache_buffer", "v_cache_buffer", "v_cache_cpu")
+    for n in names:
+        a, b = getattr(sub, n).cpu(), getattr(one, n).cpu()
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a,
+                           b.view(torch.int16) if b.dtype == torch.bfloat16 else b), f"sub-batched vs one-shot: {n}"
+    d_sub = _decode3(case, sub, inputs, list(range(B)))
+    d_one = _decode3(case, one, inputs, list(range(B)))
+    for i, (x, y) in enumerate(zip(d_sub, d_one)):
+        assert torch.equal(x["pos"], y["pos"]) and torch.equal(x["cnts"], y["cnts"]), f"call {i}: ids / counts"
+        assert_bits_equal(x["v"], y["v"], f"call {i}: V view")
+        assert_bits_equal(x["k"], y["k"], f"call {i}: K view")
+    assert sub.kv_offset == c["L"] + 3 and sub.gen_offset == 3
+    misses = sum(int((sub.select_sets - x["cnts"]).sum()) for x in d_sub)
+    assert misses > 0
+    # four single-sequence caches: sequence b of the batch behaves exactly like a batch of one
+    for b in range(B):
+        single, _ = _device_prefill(case, 1, only=b)
+        for n in names:
+            a, s1 = getattr(sub, n)[:, b:b + 1].cpu(), getattr(single, n).cpu()
+            # (the batched cache has decoded 3 steps by now: compare what decoding does not touch, then the decode itself)
+            if n in ("U", "SV", "k_landmark", "k_landmark_idx", "v_cache_cpu"):
+                assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a,
+                                   s1.view(torch.int16) if s1.dtype == torch.bfloat16 else s1), f"sequence {b}: {n}"
+        d1 = _decode3(case, single, inputs, [b])
+        for i, (x, y) in enumerate(zip(d_sub, d1)):
+            assert torch.equal(x["pos"][b:b + 1], y["pos"]) and torch.equal(x["cnts"][b:b + 1], y["cnts"]), f"sequence {b} call {i}"
+            assert_bits_equal(x["v"][b:b + 1], y["v"], f"sequence {b} call {i}: V view")
+            assert_bits_equal(x["k"][b:b + 1], y["k"], f"sequence {b} call {i}: K view")
+        del single

@@ -1,8 +1,9 @@
 """GPU, BASELINE.json sizes, on the path the headline runs by default (bench.py: in-place layout, attention inside the fetch
 launch, hipGraph, SPECULATIVE EARLY V FETCH ON with the default chunks per head): Llama-3.1-8B shapes at 124,928 tokens
 (config 1: 61 scan tiles per head, E = 32) and GLM-4-9B shapes at 204,800 tokens (config 3: 4 KV heads x 8 query heads, GLM
-RoPE, 100 scan tiles per head, E = 64), budget 2048, rank 160, 2 layers to keep the run short.  The oracle cannot follow at
-this size in seconds, so the checks are invariants the domain offers:
+RoPE, 100 scan tiles per head, E = 64), budget 2048, rank 160, 2 layers to keep the run short.
+test_captured_default_path_against_the_oracle_at_full_size compares that path with the ORACLE step by step (selection set and
+hit count per layer, V rows, attention); the other tests check invariants the domain offers over longer runs:
   * every slot of the sparse region holds exactly the V chunk its position_ids entry names (bytes from the host table:
     kv_cache.py:1081-1095 / copy.cuh:785-846 move byte-exact rows) - also for the chunks the early fetch staged in HBM
   * its K rows equal RoPE(U[rows] . SV^T) recomputed with PyTorch for the same ids (tolerance of the MFMA order)
@@ -150,6 +151,84 @@ def test_early_fetch_changes_no_bit_at_full_size(shape):
         assert all(0 < n <= E * ce.block_num for n in per_layer), (step, per_layer)
     misses = ce.block_num * ce.select_sets * me.num_layers - int(ce._cnts_layers.sum())
     assert misses > 0, "the walk produced no miss in the last step: nothing was fetched"
+
+
+@pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k"])
+def test_captured_default_path_against_the_oracle_at_full_size(shape):
+    """BASELINE.json configs 1 and 3 on the exact path bench.py times (captured step, fused selection, in-place layout, early
+    fetch with the shape's default E, attention inside the fetch launch), 2 layers, 2 eager warm-up steps + 3 replays, against
+    the oracle on the walk table's queries (about 30 ms of oracle per layer and step on the GPU box's cores):
+      * per layer and step the resident chunk SET == oracle.batch_gemm_softmax + group_max_topk (bit-exact scores, the same
+        tie rule), and the hit count == |selection & previous selection|;
+      * every slot's V rows == the host table's rows of the chunk it names, byte for byte (all layers, every step);
+      * the last layer's attention output == the oracle's over the device's own K / V bytes (check_attention with the
+        rounding labels of the fetch launch's miss tiles; `_dst_slots` / `cnts` hold the last layer's bookkeeping)."""
+    import math
+    import oracle
+    from shadowkv_amd import llama
+    from util import check_attention, overlapped_pass_labels, ALPHA
+    cfg_name, ctx, budget, n_lm, E = SHAPES[shape]
+    m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=budget, rank=160,
+                        chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
+    llama.build_synthetic_context(m, ctx, seed=11)
+    c = m.kv_cache
+    c.enable_early_fetch()
+    assert c._early["E"] == E and c.fused_select and c.k_landmark.shape[-2] == n_lm
+    kv, Hq, D, S, C = c.num_key_value_heads, c.num_attention_heads, c.head_dim, c.select_sets, c.chunk_size
+    G = Hq // kv
+    c.attn_out_tap = [torch.zeros(1, 1, Hq, D, dtype=torch.bfloat16, device=DEV) for _ in range(m.num_layers)]
+    table = llama.make_walk_table(m, 12, seed=5)                              # [T, L, 1, Hq, 1, D]
+    lm = [c.k_landmark[l][0].cpu().contiguous() for l in range(m.num_layers)]
+    lm_idx = [c.k_landmark_idx[l][0].cpu().contiguous() for l in range(m.num_layers)]
+    T = (n_lm + 255) // 256
+    resident = [[set(c.position_ids[l][0, h].tolist()) for h in range(kv)] for l in range(m.num_layers)]
+
+    def oracle_step(i):
+        """selection of step i per layer (sets per head) and the hit counts against the resident sets; advances them"""
+        hits = []
+        for l in range(m.num_layers):
+            q = table[i % table.shape[0]][l][0].cpu().view(kv, G, D).contiguous()
+            Dm = torch.zeros(kv, G, n_lm, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
+            oracle.batch_gemm_softmax(q, lm[l], Dm, torch.zeros(kv, T, G), torch.zeros(kv, T, G), P, kv, G, n_lm, D, ALPHA)
+            sel = oracle.group_max_topk(P, lm_idx[l], kv, G, n_lm, S)
+            new = [set(sel[h].tolist()) for h in range(kv)]
+            assert all(len(x) == S for x in new)
+            hits.append([len(new[h] & resident[l][h]) for h in range(kv)])
+            resident[l] = new
+        return hits
+
+    def check_state(i, hits, what):
+        for l in range(m.num_layers):
+            ids = c.position_ids[l][0].cpu()
+            for h in range(kv):
+                assert set(ids[h].tolist()) == resident[l][h], f"{shape} {what} layer {l} head {h}: resident set != oracle selection"
+            assert c._cnts_layers[l].cpu().tolist() == hits[l], f"{shape} {what} layer {l}: hit counts"
+            want_v = torch.stack([c.v_cache_cpu[l][0, h][ids[h]] for h in range(kv)]).view(kv, S * C, D)
+            got_v = c.v_cache_buffer[l][0, :, c.sparse_start:c.sparse_end].cpu()
+            assert torch.equal(got_v.view(torch.int16), want_v.view(torch.int16)), f"{shape} {what} layer {l}: V rows"
+
+    dec = llama.GraphDecoder(m, temperature=0.6, walk_table=table)
+    dec.token.copy_(torch.tensor([[7]], device=DEV))
+    warm = dec.capture()
+    assert warm == 2
+    oracle_step(0)
+    check_state(1, oracle_step(1), "after the eager warm-up steps")
+    miss_total = 0
+    for r in range(3):
+        i = warm + r
+        dec.step()
+        torch.cuda.synchronize()
+        hits = oracle_step(i)
+        check_state(i, hits, f"replay {r}")
+        miss_total += sum(S - x for row in hits for x in row)
+        l = m.num_layers - 1
+        kv_len = c.sparse_end + i + 1
+        q = table[i % table.shape[0]][l][0].cpu().view(1, Hq, D).contiguous()
+        check_attention(f"test_captured_default_path_against_the_oracle_at_full_size[{shape}] replay {r}",
+                        c.attn_out_tap[l].view(1, Hq, D).cpu().float(), q, c.k_cache_buffer[l].cpu().contiguous(),
+                        c.v_cache_buffer[l].cpu().contiguous(), kv_len, 1 / math.sqrt(D), overlapped_pass_labels(c, kv_len))
+    assert miss_total > 0
+    assert sum(int(c.early_fetch_counts(l).sum()) for l in range(m.num_layers)) > 0       # the early fetch took part
 
 
 @pytest.mark.parametrize("cfg_name,glm", [("LLAMA_3_1_8B", False), ("GLM_4_9B_1M", True)])

@@ -197,3 +197,51 @@ def test_resident_set_option_lays_out_the_buffers_and_keeps_the_reference_state(
         with pytest.raises(ValueError):
             ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
                               sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"], resident_sets=bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sub-batched prefill (VERDICT r4 missing #4): LLM.batch_prefill (/root/reference/models/base.py:533-543) prefills a batch in
+# sub-batches, every layer per sub-batch; get_svd / prefill_kv_cache keep `prefilled_batch` (kv_cache.py:683-737, 788-980).
+# tests/golden/subbatch_prefill.json: digests of the state the REFERENCE's ShadowKVCache_CPU reaches that way (batch 4 in two
+# sub-batches of 2, 2 layers), made by tests/golden/make_golden.py.
+# ---------------------------------------------------------------------------------------------------------------------
+SUB_STATE = ("U", "SV", "k_landmark", "k_landmark_idx", "position_ids", "k_cache_buffer", "v_cache_buffer", "v_cache_cpu")
+
+
+def _prefill_in_subbatches(case, sub, batch=None, only=None):
+    from shadowkv_amd.kv_cache import ShadowKVCache_CPU
+    c = G.SUBBATCH_CASES[case]
+    inputs = G.subbatch_inputs(case)
+    seqs = list(range(c["batch"])) if only is None else [only]
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=len(seqs), max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
+    progress = []
+    for i in range(0, len(seqs), sub):
+        idx = seqs[i:i + sub]
+        for l, inp in enumerate(inputs):
+            cache.get_svd(inp["k_pre"][idx], l)
+            cache.prefill_kv_cache(inp["v"][idx], l, inp["k_roped"][idx], inp["q_last"][idx])
+        progress.append({"prefilled_batch": cache.prefilled_batch, "kv_offset": cache.kv_offset, "kv_len": cache.get_kv_len()})
+    cache.H2D()
+    return cache, progress
+
+
+def test_subbatched_prefill_equals_the_reference_and_the_one_shot_build():
+    import json
+    from trace_standin import digest
+    case = "subbatch_llama"
+    c = G.SUBBATCH_CASES[case]
+    with open(os.path.join(GOLD, "subbatch_prefill.json")) as f:
+        z = json.load(f)
+    sub, progress = _prefill_in_subbatches(case, c["sub"])
+    assert progress == z["progress"]                     # prefilled_batch 2 -> 4; kv_offset moves once the whole batch is in
+    assert {n: digest(getattr(sub, n)) for n in SUB_STATE} == z["state"]
+    assert [sub.chunks, sub.prefill_local, sub.sparse_start, sub.sparse_end, sub.k_landmark.shape[-2]] == \
+        [z["meta"][k] for k in ("chunks", "prefill_local", "sparse_start", "sparse_end", "landmarks")]
+    one, p1 = _prefill_in_subbatches(case, c["batch"])   # the whole batch in one call per layer
+    assert p1 == z["progress"][-1:]
+    for n in SUB_STATE:
+        assert torch.equal(getattr(one, n), getattr(sub, n)), n
+    for b in range(c["batch"]):                           # and four single-sequence caches
+        single, _ = _prefill_in_subbatches(case, 1, only=b)
+        assert {n: digest(getattr(single, n)) for n in SUB_STATE} == z["per_sequence"][b], b
