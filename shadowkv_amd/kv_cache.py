@@ -867,30 +867,36 @@ class ShadowKVCache_CPU:
         off = int(lib().skv_select_state_stats_offset(self.block_num, G))
         return self._sel_state[layer_idx][off:off + 8 * self.block_num].view(torch.int32).view(self.block_num, 2).cpu()
 
+    def _early_published_ids(self, layer_idx):
+        """int32 [blocks, E]: the chunk id every staging slot was PUBLISHED with in the last step of this layer, -1 = unused.
+        This is the ground truth of what the fetch launch may read from staging: each pull workgroup publishes exactly the
+        slots it fills (csrc/skv_early.h), whereas the state's count word comes from ONE of a head's pull workgroups, whose
+        list may differ from its siblings' by a chunk when it read the resident map microseconds later."""
+        e = self._early
+        o, E, B = e["offsets"], e["E"], self.block_num
+        return e["states"][layer_idx][o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
+
     def early_fetch_counts(self, layer_idx):
-        """Chunks pulled early per (batch, head) in the last step of this layer (int32 [blocks]); diagnostic, synchronises."""
+        """Chunks pulled early per (batch, head) in the last step of this layer (int32 [blocks]) = the staging slots published
+        with a chunk id; diagnostic, synchronises."""
         if self._early is None:
             return None
-        e = self._early
-        o = e["offsets"]
-        return e["states"][layer_idx][o[4]:o[4] + 4 * self.block_num].view(torch.int32).cpu()
+        return (self._early_published_ids(layer_idx) >= 0).sum(dim=1).to(torch.int32)
 
     def early_fetch_stats(self, layer_idx):
         """(chunks pulled early, of these selected - i.e. read from staging by the fetch launch -, misses) summed over the
         heads; diagnostic, synchronises.  Valid for the layer launched LAST only (pass num_layers - 1 after a decode step):
-        the miss list (self.offsets) is shared by all layers and rewritten by every layer's selection; the early ids and
-        counts are per layer (early_fetch_counts works for any layer)."""
+        the miss list (self.offsets) is shared by all layers and rewritten by every layer's selection; the early ids are per
+        layer (early_fetch_counts works for any layer)."""
         if self._early is None:
             return None
-        e = self._early
-        o, E, B, S = e["offsets"], e["E"], self.block_num, self.select_sets
-        n = self.early_fetch_counts(layer_idx)
-        ids = e["states"][layer_idx][o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
+        B, S = self.block_num, self.select_sets
+        ids = self._early_published_ids(layer_idx)
         cnts = self._cnts_layers[layer_idx].view(-1).cpu()
         miss = self.offsets.view(B, S).cpu()
         pulled = used = misses = 0
         for b in range(B):
-            early = set(ids[b, :int(n[b])].tolist())
+            early = set(ids[b][ids[b] >= 0].tolist())
             m = set(miss[b, int(cnts[b]):].tolist())
             pulled += len(early); used += len(early & m); misses += len(m)
         return pulled, used, misses
