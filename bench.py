@@ -114,7 +114,8 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
             and model.kv_cache.select_sets >= 128 and (args.batch == 1 or args.early_fetch_batches)):
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
         # early fetch, 268.8 with it)
-        model.kv_cache.enable_early_fetch(early_max=None if args.early_fetch < 0 else args.early_fetch, margin=args.early_margin)
+        model.kv_cache.enable_early_fetch(early_max=None if args.early_fetch < 0 else args.early_fetch, margin=args.early_margin,
+                                          near=bool(args.near_fetch) and args.batch == 1)
     torch.cuda.synchronize()
     return model, cfg, ctx, budget, time.perf_counter() - t0
 
@@ -912,6 +913,10 @@ def main(argv=None):
                     help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
                          "top-k; -1 = the default for the shape (32 for G <= 4, 64 for G = 8 at budget 2048, scaled with the budget: kv_cache.enable_early_fetch), 0 = off")
     ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
+    ap.add_argument("--near-fetch", type=int, default=0, choices=[0, 1],
+                    help="1: the gate/up GEMV launch of every layer also stages the chunks that fell just short of the step's selection "
+                         "for the NEXT step (near misses: a third of them are selected next); needs the early fetch and the fused "
+                         "selection; identical results")
     ap.add_argument("--early-fetch-batches", type=int, default=0, choices=[0, 1],
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "
                          "off by default: measured 595.3 vs 594.9 tokens/s at bs 8, 769.3 vs 761.0 at bs 24 - the selection is a small "

@@ -310,7 +310,8 @@ static int early_offsets(int blocks, int groups, int n_landmarks, int n_chunks, 
         (const unsigned char*)e.dthr - z,      (const unsigned char*)e.finals - z,    (const unsigned char*)e.flag_cnt - z,
         (const unsigned char*)e.flag_slot - z, (const unsigned char*)e.early_cnt - z, (const unsigned char*)e.early_ids - z,
         (const unsigned char*)e.early_of - z,  (const unsigned char*)e.staging - z,   (const unsigned char*)e.gap_slots - z,
-        (const unsigned char*)e.map_ok - z};
+        (const unsigned char*)e.map_ok - z,    (const unsigned char*)e.near_cnt - z,  (const unsigned char*)e.near_ids - z,
+        (const unsigned char*)e.near_pub - z};
     for (int i = 0; i < n_out && i < SKV_EARLY_STATE_REGIONS; ++i) out[i] = all[i];
     return SKV_OK;
 }
@@ -320,7 +321,8 @@ int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunk
     return early_offsets(blocks, groups, n_landmarks, n_chunks, early_max, out8, 8);
 }
 
-// the first n_out (<= SKV_EARLY_STATE_REGIONS = 10) entries: 8 = the slot -> chunk-id gap table i32 [B][128], 9 = its validity flag
+// the first n_out (<= SKV_EARLY_STATE_REGIONS = 13) entries: 8 = the slot -> chunk-id gap table i32 [B][128], 9 = its validity flag,
+// 10 = near-miss count i32 [B], 11 = near-miss list i32 [B][64], 12 = near misses staged now i32 [B][64] (slots E .. E + 63 of 7)
 int skv_early_state_offsets2(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out, int n_out) {
     return early_offsets(blocks, groups, n_landmarks, n_chunks, early_max, out, n_out);
 }
@@ -355,11 +357,8 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
-                  es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
-                  (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
-    eh.gap_slots = es.gap_slots;
-    eh.map_ok = es.map_ok;
+    EarlyHooks eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
+                                    resident_sets, n_chunks, early_max);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;
     rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
@@ -412,11 +411,8 @@ int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t*
         if (!landmark_idx || !v_host || (host_block_stride % 8) || n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
         if (n_landmarks > 65536 || resident_sets > 1024 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
         const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-        eh = EarlyHooks{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
-                        es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
-                        (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, early_max};
-        eh.gap_slots = es.gap_slots;
-        eh.map_ok = es.map_ok;
+        eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks, resident_sets,
+                             n_chunks, early_max);
         hooks = &eh;
     }
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, hooks, &fs);
@@ -440,11 +436,8 @@ int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t*
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, cached_pos_ids,
-                  es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
-                  (n_landmarks + 255) / 256, n_landmarks, select_sets, n_chunks, early_max};
-    eh.gap_slots = es.gap_slots;
-    eh.map_ok = es.map_ok;
+    EarlyHooks eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
+                                    select_sets, n_chunks, early_max);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;
     rc = skv_launch_normalize_groupmax(w.D, w.pmax, w.psum, softmax_out, w.score, w.score_stride, blocks, groups,
@@ -467,7 +460,7 @@ int skv_fetch_kv_early(const void* U, const void* SV, const void* cos_sin, const
     if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
-    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max};
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX};   // (slots [E, E + NEAR): near misses)
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, k_temp, offsets, nullptr, v_host, v_cache, v_temp,
@@ -580,7 +573,7 @@ int skv_fetch_kv_inplace_early(const void* U, const void* SV, const void* cos_si
     if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
-    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max};
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX};   // (slots [E, E + NEAR): near misses)
     return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
@@ -639,7 +632,7 @@ int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* c
                                       kv_len_dev, kv_len, kv_rows, batch_size, heads, q_heads, seq_len, head_dim, rank,
                                       select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h, cache_stride_s,
                                       sparse_start, rope_mode, host_block_stride, attn_splits, resident_sets, scale, stream,
-                                      es.early_of, es.staging, n_chunks, early_max);
+                                      es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX);
 }
 
 int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,

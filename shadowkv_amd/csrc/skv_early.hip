@@ -5,13 +5,15 @@
 #include "skv_launch.h"
 
 __global__ void skv_early_init_kernel(float* dthr, int n_dthr, int* ints, int n_ints, int* early_ids, int n_ids, short* early_of,
-                                      long long n_of, int* map_ok, int n_map) {
+                                      long long n_of, int* map_ok, int n_map, int* near_cnt, int* near_ids, int* near_pub) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     for (long long k = i; k < n_dthr; k += stride) dthr[k] = INFINITY;
     for (long long k = i; k < n_ints; k += stride) ints[k] = 0;
     for (long long k = i; k < n_ids; k += stride) early_ids[k] = -1;  // every staging slot unused
     for (long long k = i; k < n_of; k += stride) early_of[k] = (short)-1;
     for (long long k = i; k < n_map; k += stride) map_ok[k] = 0;      // no slot -> id map yet: the list role gathers
+    for (long long k = i; k < n_map; k += stride) near_cnt[k] = 0;    // (n_map = B) no near-miss list, nothing staged ahead
+    for (long long k = i; k < (long long)n_map * SKV_NEAR_MAX; k += stride) near_ids[k] = near_pub[k] = -1;
 }
 
 // slot -> chunk id map of one head (EarlyHooks::gap_slots): the landmark ids lm_idx[b][0 .. N) are chunk ids in ascending order
@@ -46,7 +48,7 @@ int skv_launch_early_init(const EarlyState& es, int B, int G, int n_landmarks, i
     // flag_cnt .. early_cnt are contiguous int regions (see skv_carve_early): zero from flag_cnt to the end of early_cnt
     const long long n_ints = ((unsigned char*)es.early_ids - (unsigned char*)es.flag_cnt) / 4;
     hipLaunchKernelGGL(skv_early_init_kernel, dim3(256), dim3(256), 0, st, es.dthr, B * G, es.flag_cnt, (int)n_ints, es.early_ids,
-                       B * E, es.early_of, (long long)B * n_chunks, es.map_ok, B);
+                       B * E, es.early_of, (long long)B * n_chunks, es.map_ok, B, es.near_cnt, es.near_ids, es.near_pub);
     return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
 }
 

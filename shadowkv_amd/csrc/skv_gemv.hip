@@ -12,6 +12,7 @@
 // 64 lanes with a DPP butterfly + two cross-row shuffles; lane 0 writes.
 #include "../../include/shadowkv_hip.h"
 #include "skv_common.h"
+#include "skv_early.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -38,18 +39,31 @@ struct QkvEpilogue {
 // RMAX (lm_head, N % 16 == 0): the workgroup also leaves the LARGEST of its 16 outputs as an order-preserving 16-bit key in
 // range_max[blockIdx.x] - the sampler (skv_sample.hip) then finds the rows that can hold a top-k logit from N / 16 keys
 // instead of streaming all N logits through one CU.
-template <int R, bool SILU_PAIR, bool NORM, bool QKV, bool RMAX = false>
+// NEARP (round 5, the gate/up launch of a ShadowKV layer): the first np.blocks workgroups do not compute - they stage the
+// near misses of this step's selection ahead of the next step (skv_near_pull_role, skv_early.h) while the GEMV streams; the
+// GEMV's own workgroups follow them in the grid.
+template <int R, bool SILU_PAIR, bool NORM, bool QKV, bool RMAX = false, bool NEARP = false>
 __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N,
                                                        int K, int I /* SILU_PAIR: rows of one half */,
                                                        const bf16_t* __restrict__ residual,
                                                        const bf16_t* __restrict__ w_norm, bf16_t* __restrict__ h_out,
-                                                       float eps, QkvEpilogue qe, uint16_t* __restrict__ range_max = nullptr) {
+                                                       float eps, QkvEpilogue qe, uint16_t* __restrict__ range_max = nullptr,
+                                                       NearPull np = NearPull{}) {
+    int bx = blockIdx.x;
+    if constexpr (NEARP) {
+        if (bx < np.blocks) {
+            __shared__ int s_near[4 * SKV_NEAR_MAX + 8];
+            skv_near_pull_role(np, bx, threadIdx.x, s_near);
+            return;
+        }
+        bx -= np.blocks;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksteps = NORM ? 8 : K / 512;  // 64 lanes x 8 elements per step (NORM: K == 4096, static trip count)
     // rows of this wave
     int rows[R];
-    const int unit0 = (blockIdx.x * 4 + wave) * (SILU_PAIR ? R / 2 : R);
+    const int unit0 = (bx * 4 + wave) * (SILU_PAIR ? R / 2 : R);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (SILU_PAIR) rows[r] = (r & 1) ? I + unit0 + r / 2 : unit0 + r / 2;  // (gate, up) pairs
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
                 ss = __builtin_fmaf(bf_hi(a[j]), bf_hi(a[j]), ss);
             }
         }
-        if (h_out && blockIdx.x == 0) {
+        if (h_out && bx == 0) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) reinterpret_cast<u32x4*>(h_out)[tid + it * 256] = hx[it];
         }
@@ -268,18 +282,26 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     }
     if constexpr (RMAX && !SILU_PAIR && !QKV) {      // (N % 16 == 0: every wave of every workgroup arrives here)
         __syncthreads();
-        if (tid == 0) range_max[blockIdx.x] = (uint16_t)max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
+        if (tid == 0) range_max[bx] = (uint16_t)max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
     }
 }
 
 static int launch_gemv(const void* W, const void* x, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                        const void* residual, const void* w_norm, void* h_out, float eps, bool norm, hipStream_t st,
-                       const QkvEpilogue* qkv = nullptr, uint16_t* range_max = nullptr) {
+                       const QkvEpilogue* qkv = nullptr, uint16_t* range_max = nullptr, const NearPull* near = nullptr) {
     if (!W || !x || (!y && !qkv) || N < 1) return SKV_ERR_ARG;
     QkvEpilogue qe{};
     if (qkv) qe = *qkv;
     if (K % 8 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
+    if (near) {          // the gate/up launch of a layer with the near-miss pull role in front of its grid
+        if (!norm || !fuse_silu_mul || qkv || range_max || (N % 2) || bias || near->blocks < 1) return SKV_ERR_UNSUPPORTED;
+        const int I = N / 2, grid = (I + 7) / 8;
+        hipLaunchKernelGGL((skv_gemv_kernel<4, true, true, false, false, true>), dim3(near->blocks + grid), dim3(256), 0, st,
+                           (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, I, (const bf16_t*)residual,
+                           (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe, (uint16_t*)nullptr, *near);
+        return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
+    }
     if (range_max) {     // the lm_head with the sampler's range keys: norm prologue, whole workgroups of 16 rows
         if (!norm || qkv || fuse_silu_mul || N % 16) return SKV_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((skv_gemv_kernel<4, false, true, false, true>), dim3(N / 16), dim3(256), 0, st, (const bf16_t*)W,
@@ -332,6 +354,19 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
                                   void* h_out, const void* bias, void* y, int N, int K, int fuse_silu_mul,
                                   skv_stream_t stream) {
     return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, residual, norm_weight, h_out, eps, true, (hipStream_t)stream);
+}
+
+extern "C" int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                                            void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
+                                            int n_landmarks, int n_chunks, int early_max, const void* v_host,
+                                            long long host_block_stride, skv_stream_t stream) {
+    if (!early_state || !v_host || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1 || early_max > 128 ||
+        (host_block_stride % 8))
+        return SKV_ERR_ARG;
+    if (n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;      // (the early state's limit, skv_select_chunks_fused)
+    const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
+    const NearPull np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max);
+    return launch_gemv(W, x, nullptr, y, N, K, 1, residual, norm_weight, h_out, eps, true, (hipStream_t)stream, nullptr, nullptr, &np);
 }
 
 extern "C" int skv_norm_gemv_rangemax_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,

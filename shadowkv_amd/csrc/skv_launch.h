@@ -80,6 +80,14 @@ struct EarlyHooks {
     // ascending order minus a few (the outlier chunks), so id(slot) = slot + #{i : gap_slots[i] <= slot}; map_ok[b] == 0: gather
     const int* gap_slots;       // [B][SKV_EARLY_GAPS] ascending, INT_MAX padded
     const int* map_ok;          // [B]
+    // near-miss staging for the NEXT step (round 5, see EarlyState): the top-k launch leaves up to SKV_NEAR_MAX chunk ids that
+    // fell just short of this step's selection (near_ids / near_cnt, prediction only); the pull role of the gate/up GEMV
+    // launch stages them (skv_near_pull_role) and publishes them in early_of with staging indices E .. E + SKV_NEAR_MAX - 1;
+    // near_pub = the ids published there now (-1: slot unused) - the in-step list treats them like resident chunks.
+    int* near_cnt;              // [B]
+    int* near_ids;              // [B][SKV_NEAR_MAX]
+    const int* near_pub;        // [B][SKV_NEAR_MAX]
+    int stage_stride;           // staging slots per (batch, head): E + SKV_NEAR_MAX
 };
 
 // Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.
@@ -90,8 +98,13 @@ struct EarlyHooks {
 //   early_cnt [B]       i32   chunks the early launch pulled this step, early_ids [B][E] their chunk ids
 //   early_of  [B][chunks] i16 staging index of a chunk pulled early this step, -1 otherwise
 //   staging   [B][E][2 KiB]   the pulled V chunks
+//   near_cnt  [B] i32, near_ids [B][SKV_NEAR_MAX] i32   round 5: chunks just below this step's selection (written by the top-k
+//                              launch), candidates for staging ahead of the NEXT step; near_pub [B][SKV_NEAR_MAX] i32 the chunks
+//                              staged that way now: chunk near_pub[b][e] sits in staging slot E + e, early_of[chunk] = E + e
+//   staging is [B][E + SKV_NEAR_MAX][2 KiB]: slots [0, E) belong to the in-step early fetch, [E, E + SKV_NEAR_MAX) to the near misses
 #define SKV_EARLY_K 16
 #define SKV_EARLY_GAPS 128     // chunks that may be missing from a head's ascending landmark-id sequence (outliers: 24 per 1024 budget)
+#define SKV_NEAR_MAX 64        // near-miss staging slots per (batch, head)
 struct EarlyState {
     float* dthr;
     float* finals;
@@ -103,6 +116,9 @@ struct EarlyState {
     void* staging;
     int* gap_slots;
     int* map_ok;
+    int* near_cnt;
+    int* near_ids;
+    int* near_pub;
     size_t total;
 };
 static inline size_t skv_early_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -118,9 +134,44 @@ static inline EarlyState skv_carve_early(void* base, int B, int G, int n_landmar
     e.early_cnt = (int*)(p + off);   off += skv_early_align((size_t)B * 4);
     e.early_ids = (int*)(p + off);   off += skv_early_align((size_t)B * E * 4);
     e.early_of = (short*)(p + off);  off += skv_early_align((size_t)B * n_chunks * 2);
-    e.staging = p + off;             off += skv_early_align((size_t)B * E * 2048);
+    e.staging = p + off;             off += skv_early_align((size_t)B * (E + SKV_NEAR_MAX) * 2048);
     e.gap_slots = (int*)(p + off);   off += skv_early_align((size_t)B * SKV_EARLY_GAPS * 4);
     e.map_ok = (int*)(p + off);      off += skv_early_align((size_t)B * 4);
+    e.near_cnt = (int*)(p + off);    off += skv_early_align((size_t)B * 4);
+    e.near_ids = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_MAX * 4);
+    e.near_pub = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_MAX * 4);
     e.total = off;
     return e;
+}
+// the selection launches' view of a carved state (one place: every entry that takes an early state builds its hooks here)
+static inline EarlyHooks skv_early_hooks(const EarlyState& es, int groups, float margin, const int64_t* landmark_idx,
+                                         const int64_t* resident, const void* v_host, long long host_block_stride,
+                                         int n_landmarks, int resident_sets, int n_chunks, int E) {
+    EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, resident,
+                  es.early_cnt, es.early_ids, es.early_of, v_host, host_block_stride / 8, es.staging,
+                  (n_landmarks + 255) / 256, n_landmarks, resident_sets, n_chunks, E};
+    eh.gap_slots = es.gap_slots;
+    eh.map_ok = es.map_ok;
+    eh.near_cnt = es.near_cnt;
+    eh.near_ids = es.near_ids;
+    eh.near_pub = es.near_pub;
+    eh.stage_stride = E + SKV_NEAR_MAX;
+    return eh;
+}
+
+// Near-miss staging ahead of the next step (round 5): the pull role that rides in the gate/up GEMV launch of a layer
+// (skv_gemv.hip: the first `blocks` workgroups of that launch; skv_near_pull_role in skv_early.h).
+struct NearPull {
+    const int* near_cnt;        // [B]   (top-k launch of this step)
+    const int* near_ids;        // [B][SKV_NEAR_MAX]
+    int* near_pub;              // [B][SKV_NEAR_MAX] in / out: what staging slots E .. hold
+    short* early_of;            // [B][n_chunks]
+    void* staging;              // [B][E + SKV_NEAR_MAX][2 KiB]
+    const void* v_host;
+    long long v_host_stride_u128;
+    int blocks;                 // B = batch x KV heads: one pull workgroup each
+    int n_chunks, E;
+};
+static inline NearPull skv_near_pull(const EarlyState& es, const void* v_host, long long host_block_stride, int B, int n_chunks, int E) {
+    return NearPull{es.near_cnt, es.near_ids, es.near_pub, es.early_of, es.staging, v_host, host_block_stride / 8, B, n_chunks, E};
 }

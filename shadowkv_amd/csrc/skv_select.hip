@@ -1046,6 +1046,22 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
                 s_id[gt_run + eq_run] = idb;
             }
             TOPK_STAMP(18);
+            if (eh.near_ids != nullptr) {
+                // Near misses (round 5; prediction only, nothing downstream of the selection reads it): the candidates that were
+                // evaluated exactly and fell short of the S-th score are the chunks most likely to enter the NEXT step's selection
+                // (tools/near_miss_sim.py: a third of the 64 nearest do).  The first SKV_NEAR_MAX of them in slot order go to
+                // near_ids; the gate/up GEMV launch of this layer stages them while the link is idle (skv_near_pull_role).
+                // One more block scan: the selection workgroup finishes microseconds before the launch's pull workgroups.
+                const int la = va && lo < thr, lb = vb && hi < thr;
+                const int nincl = block_scan_incl1(la + lb, searched ? s_w + 48 : s_w + 32, tid);   // (the row the last scan did not use)
+                int npos = nincl - (la + lb);
+                if (la) {
+                    if (npos < SKV_NEAR_MAX) eh.near_ids[(size_t)b * SKV_NEAR_MAX + npos] = (int)ida;
+                    ++npos;
+                }
+                if (lb && npos < SKV_NEAR_MAX) eh.near_ids[(size_t)b * SKV_NEAR_MAX + npos] = (int)idb;
+                if (tid == T2_THREADS - 1) eh.near_cnt[b] = min(nincl, SKV_NEAR_MAX);
+            }
             return true;
         }
         if (tid == 0) ft.stats[2 * b] |= 2;

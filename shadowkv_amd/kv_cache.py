@@ -266,6 +266,10 @@ class ShadowKVCache_CPU:
         # current stream and (start, end, layer) is appended; None (default): nothing is recorded
         self.fetch_events = None
         self.attn_out_tap = None         # test hook: see select_fetch_attend_inplace
+        # Near-miss staging ahead of the next step (round 5; needs the early fetch and the fused selection): the gate/up GEMV
+        # launch of every layer stages the chunks that fell just short of this step's selection (near_pull_args ->
+        # tensor_op.norm_linear_decode(near_pull=)); the next step's fetch launch reads them from HBM.  Identical results.
+        self.near_fetch = False
         self._copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -808,7 +812,7 @@ class ShadowKVCache_CPU:
             return torch.cuda.current_stream(self.device)
         return self._copy_stream
 
-    def enable_early_fetch(self, early_max=None, margin=0.0):
+    def enable_early_fetch(self, early_max=None, margin=0.0, near=None):
         """Speculative early V fetch for select_fetch_attend_inplace (csrc/skv_early.hip): the scan launch flags the
         landmark slots that would have made the PREVIOUS step's top-k, an extra workgroup of the normalise launch lists up
         to `early_max` of their non-resident chunks per head, an extra workgroup of the top-k launch pulls those from the
@@ -818,7 +822,11 @@ class ShadowKVCache_CPU:
         MI355X with the fused selection (profiles/r04_fused_selection.txt: 28 / 32 / 40 / 56 chunks 222.5 / 224.8 / 224.4 / 224.1
         tokens/s at config 1; 48 / 64 / 80 198.0 / 198.0 / 195.2 at config 3; 48 / 64 / 96 / 112 / 128 173.0 / 174.2 / 179.7 / 179.9 /
         177.7 at 244K with budget 4096 - its selection runs longer, more of the link's work fits beside it; 16 / 24 / 32 261.5 / 261.8 /
-        260.3 at 60K with budget 1024); 0 / False switches it off again."""
+        260.3 at 60K with budget 1024); 0 / False switches it off again.
+        near (round 5): True / False sets `near_fetch` - the gate/up GEMV launch of every layer then also stages the chunks that
+        fell just short of the step's selection for the NEXT step (near_pull_args); None leaves the attribute as it is."""
+        if near is not None:
+            self.near_fetch = bool(near)
         if not early_max and early_max is not None:
             if self._early is not None:      # a captured step may still point at the state buffers: they stay allocated
                 self._early_retired = getattr(self, "_early_retired", []) + [self._early]
@@ -848,8 +856,8 @@ class ShadowKVCache_CPU:
             # list role then needs no dependent gather; any other landmark_idx is detected on the device and keeps the gather
             check(L.skv_early_state_set_landmark_map(ptr(states[l]), ptr(self.k_landmark_idx[l]), self.block_num,
                                                      self.num_key_value_groups, n_lm, n_chunks, E, st), "early_state_set_landmark_map")
-        offs = (ctypes.c_longlong * 10)()
-        check(L.skv_early_state_offsets2(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs, 10), "early_state_offsets")
+        offs = (ctypes.c_longlong * 13)()
+        check(L.skv_early_state_offsets2(self.block_num, self.num_key_value_groups, n_lm, n_chunks, E, offs, 13), "early_state_offsets")
         torch.cuda.synchronize(self.device)
         if self._early is not None:
             self._early_retired = getattr(self, "_early_retired", []) + [self._early]
@@ -866,6 +874,23 @@ class ShadowKVCache_CPU:
             return None
         off = int(lib().skv_select_state_stats_offset(self.block_num, G))
         return self._sel_state[layer_idx][off:off + 8 * self.block_num].view(torch.int32).view(self.block_num, 2).cpu()
+
+    def near_pull_args(self, layer_idx):
+        """Arguments of tensor_op.norm_linear_decode(..., near_pull=) for this layer's gate/up launch, or None when the
+        near-miss staging is off (`near_fetch`, enable_early_fetch(near=True)): (early state, blocks, groups, landmarks,
+        chunks, early_max, V table, its per-head stride)."""
+        ea = self._early
+        if ea is None or not self.near_fetch or not self.fused_select or self._sel_state is None:
+            return None
+        vhost = self.v_cache_cpu[layer_idx]
+        return (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],
+                ptr(vhost), vhost.stride(1))
+
+    def near_published_ids(self, layer_idx):
+        """int32 [blocks, 64]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 63; -1 = empty."""
+        e = self._early
+        o, B = e["offsets"], self.block_num
+        return e["states"][layer_idx][o[12]:o[12] + 4 * B * 64].view(torch.int32).view(B, 64).cpu()
 
     def _early_published_ids(self, layer_idx):
         """int32 [blocks, E]: the chunk id every staging slot was PUBLISHED with in the last step of this layer, -1 = unused.

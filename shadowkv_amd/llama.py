@@ -341,7 +341,8 @@ class DecoderLM:
             # and hidden == 4096, bit-identical to add_rmsnorm + GEMV; otherwise norm_linear_decode splits it)
             residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
                                                          layer.post_attention_layernorm_variance_epsilon,
-                                                         layer.gate_up_proj, fuse_silu_mul=True)
+                                                         layer.gate_up_proj, fuse_silu_mul=True,
+                                                         near_pull=None if full or bs != 1 else c.near_pull_args(l))
             x = tensor_op.linear_decode(act, layer.down_proj)
         V = self.lm_head.shape[0]
         rm = None

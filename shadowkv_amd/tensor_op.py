@@ -64,14 +64,27 @@ def range_max_supported(x_numel, K, N):
     return x_numel == K == 4096 and N % 16 == 0 and N // 16 <= 16384
 
 
-def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False, out=None, h_out=None, range_max=None):
+def norm_linear_decode(x, residual, norm_w, eps, w, bias=None, fuse_silu_mul=False, out=None, h_out=None, range_max=None,
+                       near_pull=None):
     """(h, y): h = x + residual (residual None -> h = x), y = linear(RMSNorm(h) * norm_w) for one token, one
     native launch when the hidden size is 4096; otherwise add_rmsnorm + linear_decode.  out / h_out: caller-owned
     result buffers (the eager decode paths reuse theirs instead of allocating per call).
     range_max (lm_head only; int16 [>= N // 16], 16-B aligned; range_max_supported(...) must hold): the launch also leaves the
-    largest of every 16 outputs as the sampler's 16-bit key (sample_token_native(..., range_max=))."""
+    largest of every 16 outputs as the sampler's 16-bit key (sample_token_native(..., range_max=)).
+    near_pull (gate/up launch of a ShadowKV layer only; ShadowKVCache_CPU.near_pull_args(layer)): the launch's first workgroups
+    stage the near misses of this step's selection ahead of the next step (skv_norm_gemv_near_pull_bf16); same y."""
     K = x.shape[-1]
     N = w.shape[0]
+    if near_pull is not None:
+        if not fuse_silu_mul or bias is not None or range_max is not None or x.numel() != K or K != 4096 \
+                or not x.is_contiguous() or not w.is_contiguous():
+            raise ValueError("near_pull rides in the one-token gate/up launch (hidden size 4096, fused SiLU * mul, no bias)")
+        y = out if out is not None else torch.empty(x.shape[:-1] + (N // 2,), dtype=x.dtype, device=x.device)
+        h = (h_out if h_out is not None else torch.empty_like(x)) if residual is not None else x
+        check(lib().skv_norm_gemv_near_pull_bf16(ptr(w), ptr(x), ptr(residual), ptr(norm_w), float(eps),
+                                                 ptr(h) if residual is not None else 0, ptr(y), N, K, *near_pull,
+                                                 current_stream_handle()), "norm_gemv_near_pull")
+        return h, y
     if range_max is not None:
         if fuse_silu_mul or not range_max_supported(x.numel(), K, N) or not x.is_contiguous() or not w.is_contiguous():
             raise ValueError("range_max: one token, hidden size 4096, N % 16 == 0, N <= 262,144, no fused SiLU")

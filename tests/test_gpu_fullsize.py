@@ -29,11 +29,11 @@ REPLAYS = 6
 _RUNS = {}
 
 
-def _run(shape, early):
-    """One model of `shape` decoded for 2 eager warm-up steps + REPLAYS captured steps; cached per (shape, early) so that
+def _run(shape, early, near=False):
+    """One model of `shape` decoded for 2 eager warm-up steps + REPLAYS captured steps; cached per (shape, early, near) so that
     the comparison test reuses the fixtures' runs.  Returns (model, tokens of the replays, chunks pulled early per replay
     and layer or None)."""
-    key = (shape, early)
+    key = (shape, early, near)
     if key in _RUNS:
         return _RUNS[key]
     from shadowkv_amd import llama
@@ -42,16 +42,23 @@ def _run(shape, early):
                         chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
     llama.build_synthetic_context(m, ctx, seed=11)
     if early:
-        m.kv_cache.enable_early_fetch()                 # the default E of the shape: what bench.py's headline runs with
+        m.kv_cache.enable_early_fetch(near=near)        # the default E of the shape: what bench.py's headline runs with
     table = llama.make_walk_table(m, 12, seed=5)
     dec = llama.GraphDecoder(m, temperature=0.6, walk_table=table)
     dec.token.copy_(torch.tensor([[7]], device=DEV))
     dec.capture()
     tokens, pulled = [], []
+    m.near_served = 0
     for _ in range(REPLAYS):
+        c = m.kv_cache
+        ahead = [[set(r[r >= 0].tolist()) for r in c.near_published_ids(l)] for l in range(m.num_layers)] if near else None
         tokens.append(int(dec.step()[0, 0]))            # (reads the token back: one sync per step, as bench.py does)
         if early:
             pulled.append([int(m.kv_cache.early_fetch_counts(l).sum()) for l in range(m.num_layers)])
+        if near:        # misses of the LAST layer (whose miss list the shared buffers still hold) served from chunks staged ahead
+            l = m.num_layers - 1
+            cnts, miss = c._cnts_layers[l].view(-1).cpu(), c.offsets.view(c.block_num, c.select_sets).cpu()
+            m.near_served += sum(len(ahead[l][b] & set(miss[b, int(cnts[b]):].tolist())) for b in range(c.block_num))
     torch.cuda.synchronize()
     m.shape_name = shape
     _RUNS[key] = (m, tokens, pulled if early else None)
@@ -151,6 +158,25 @@ def test_early_fetch_changes_no_bit_at_full_size(shape):
         assert all(0 < n <= E * ce.block_num for n in per_layer), (step, per_layer)
     misses = ce.block_num * ce.select_sets * me.num_layers - int(ce._cnts_layers.sum())
     assert misses > 0, "the walk produced no miss in the last step: nothing was fetched"
+
+
+@pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k"])
+def test_near_miss_staging_changes_no_bit_at_full_size(shape):
+    """Round 5: the captured step with the gate/up launches staging near misses ahead of the next step, against the same
+    captured steps with the early fetch alone, at the headline sizes: sampled tokens, slot -> chunk map, hit counts and both
+    caches bit for bit; and misses ARE served from the chunks staged ahead."""
+    mn, tok_n, _ = _run(shape, True, near=True)
+    me, tok_e, _ = _run(shape, True)
+    cn, ce = mn.kv_cache, me.kv_cache
+    assert cn.near_fetch and not ce.near_fetch
+    assert tok_n == tok_e, (tok_n, tok_e)
+    assert torch.equal(cn.position_ids, ce.position_ids)
+    assert torch.equal(cn._cnts_layers, ce._cnts_layers)
+    assert torch.equal(cn.v_cache_buffer.view(torch.int16), ce.v_cache_buffer.view(torch.int16))
+    assert torch.equal(cn.k_cache_buffer.view(torch.int16), ce.k_cache_buffer.view(torch.int16))
+    assert mn.near_served > 0
+    for l in range(mn.num_layers):
+        assert int((cn.near_published_ids(l) >= 0).sum()) > 0
 
 
 @pytest.mark.parametrize("shape", ["llama31_122k", "glm4_200k"])

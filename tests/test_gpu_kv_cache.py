@@ -516,28 +516,135 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
         big.get_retrieval_position_ids(0, q)
 
 
+NEAR = 64     # SKV_NEAR_SLOTS: near-miss staging slots per (batch, head) behind the E in-step slots
+
+
 def _check_staging_invariant(cache, layer):
-    """What the fetch launch relies on when it reads a chunk from staging instead of the host: early_of[chunk] = e implies
-    early_ids[e] == chunk and staging[e] holds that chunk's bytes - for every entry, whichever workgroup published it (each
-    pull workgroup of the fused selection publishes only the slots it fills, skv_early.h)."""
+    """What the fetch launch relies on when it reads a chunk from staging instead of the host: early_of[chunk] = e implies that
+    staging slot e holds that chunk's bytes and is published under its id - early_ids[e] for the in-step slots e < E (whichever
+    workgroup published it: each pull workgroup of the fused selection publishes only the slots it fills, skv_early.h),
+    near_pub[e - E] for the slots E .. E + 63 staged ahead by the gate/up launch (round 5, skv_near_pull_role)."""
     ea = cache._early
     o, st = ea["offsets"], ea["states"][layer]
     B, E, nch = cache.block_num, ea["E"], ea["n_chunks"]
     ids = st[o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
+    near = st[o[12]:o[12] + 4 * B * NEAR].view(torch.int32).view(B, NEAR).cpu()
     of = st[o[6]:o[6] + 2 * B * nch].view(torch.int16).view(B, nch).cpu()
-    staging = st[o[7]:o[7] + B * E * 2048].view(torch.int16).view(B, E, 1024).cpu()
+    staging = st[o[7]:o[7] + B * (E + NEAR) * 2048].view(torch.int16).view(B, E + NEAR, 1024).cpu()
     vh = cache.v_cache_cpu[layer].view(B, nch, 1024)
     for b in range(B):
         named = (of[b] >= 0).nonzero().view(-1)
         for c in named.tolist():
             e = int(of[b, c])
-            assert e < E and int(ids[b, e]) == c, (b, c, e, int(ids[b, e]))
+            assert e < E + NEAR, (b, c, e)
+            pub = int(ids[b, e]) if e < E else int(near[b, e - E])
+            assert pub == c, (b, c, e, pub)
             assert torch.equal(staging[b, e], vh[b, c].view(torch.int16)), (b, c, e)
         live = ids[b][ids[b] >= 0]
         assert live.unique().numel() == live.numel()             # one list: no chunk staged twice
+        nlive = near[b][near[b] >= 0]
+        assert nlive.unique().numel() == nlive.numel()
+        for e, c in enumerate(near[b].tolist()):                 # a slot staged ahead holds its chunk whether or not the map names it
+            if c >= 0:
+                assert torch.equal(staging[b, E + e], vh[b, c].view(torch.int16)), (b, e, c)
         # (a chunk staged by one workgroup whose LAST step's entry another workgroup resets in the same launch ends with its
         # new entry or with -1 - the two stores are unordered across XCDs; -1 only means the fetch launch reads it from the host)
-        assert set(named.tolist()) <= set(live.tolist())
+        assert set(named.tolist()) <= set(live.tolist()) | set(nlive.tolist())
+
+
+def _gate_up_with_near_pull(cache, layer, g):
+    """One gate/up launch (residual add + RMSNorm + [gate; up] GEMV + SiLU * mul, hidden 4096) with the near-miss pull role in
+    front of its grid, against the plain launch on the same inputs: the GEMV's own result must not change."""
+    from shadowkv_amd import tensor_op
+    x = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    res = torch.randn(1, 1, 4096, device=DEV, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(4096, device=DEV, generator=g)).bfloat16()
+    w = (torch.randn(2 * 512, 4096, device=DEV, generator=g) * 0.02).bfloat16()
+    h0, y0 = tensor_op.norm_linear_decode(x, res, nw, 1e-5, w, fuse_silu_mul=True)
+    args = cache.near_pull_args(layer)
+    assert args is not None
+    h1, y1 = tensor_op.norm_linear_decode(x, res, nw, 1e-5, w, fuse_silu_mul=True, near_pull=args)
+    torch.cuda.synchronize()
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16)) and torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+
+
+@pytest.mark.parametrize("kv_heads,glm,budget", [(8, False, 2048), (4, True, 2048), (8, False, 1024)])
+def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
+    """Round 5: the gate/up GEMV launch stages the chunks that fell just short of this step's selection for
+    the NEXT step (skv_norm_gemv_near_pull_bf16).  Against the same steps with the early fetch alone: attention output,
+    selection bookkeeping and both caches bit for bit; the GEMV's own output unchanged; the published state consistent after
+    every launch; and chunks staged ahead ARE what the next step's fetch launch needed (some misses are served from them)."""
+    L = 16384
+    ca, cs, g = _headline_cache(kv_heads, glm, L=L, seed=41, budget=budget)
+    cb, _, _ = _headline_cache(kv_heads, glm, L=L, seed=41, budget=budget)
+    ca.enable_early_fetch(near=True)
+    cb.enable_early_fetch()
+    assert ca.near_pull_args(0) is not None and cb.near_pull_args(0) is None
+    kv_len = ca.sparse_end + 2
+    q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
+    gw = torch.Generator(device=DEV).manual_seed(3)
+    B, S = ca.block_num, ca.select_sets
+    served = staged_total = 0
+    for step in range(8):
+        q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+        before = [set(r[r >= 0].tolist()) for r in ca.near_published_ids(0)]        # staged ahead, as this step's fetch sees it
+        oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        torch.cuda.synchronize()
+        _check_staging_invariant(ca, 0)
+        assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), step
+        assert torch.equal(ca.position_ids, cb.position_ids) and torch.equal(ca._cnts_layers, cb._cnts_layers)
+        assert torch.equal(ca.offsets, cb.offsets)
+        assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16)), step
+        assert torch.equal(ca.k_cache_buffer.view(torch.int16), cb.k_cache_buffer.view(torch.int16)), step
+        cnts, miss = ca.cnts.view(-1).cpu(), ca.offsets.view(B, S).cpu()
+        for b in range(B):
+            served += len(before[b] & set(miss[b, int(cnts[b]):].tolist()))
+        # the in-step list leaves the chunks staged ahead alone
+        ins = ca._early_published_ids(0)
+        for b in range(B):
+            assert not (set(ins[b][ins[b] >= 0].tolist()) & before[b]), (step, b)
+        _gate_up_with_near_pull(ca, 0, gw)
+        _check_staging_invariant(ca, 0)
+        staged_total += int((ca.near_published_ids(0) >= 0).sum())
+    assert staged_total > 0 and served > 0, (staged_total, served)
+    try:
+        from util import open_parity_record
+        with open_parity_record("near_miss_staging.txt") as f:
+            f.write(f"kv {kv_heads} glm {int(glm)} budget {budget}: misses of 7 steps served from the chunks staged ahead: {served}; "
+                    f"slots staged ahead after the last step: {int((ca.near_published_ids(0) >= 0).sum())} of {B * NEAR}\n")
+    except OSError:
+        pass
+
+
+def test_near_miss_staging_survives_clear_and_a_new_prompt():
+    """clear() retires the per-prompt early state with its near-miss slots; H2D() after the next prefill re-creates it (empty):
+    nothing staged for the old prompt can be read for the new one."""
+    ca, cs, g = _headline_cache(8, False, L=16384, seed=43)
+    ca.enable_early_fetch(near=True)
+    kv_len = ca.sparse_end + 2
+    gw = torch.Generator(device=DEV).manual_seed(5)
+    q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
+    for _ in range(3):
+        q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+        ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        _gate_up_with_near_pull(ca, 0, gw)
+    assert int((ca.near_published_ids(0) >= 0).sum()) > 0
+    ca.clear()
+    cs, g = _headline_prefill(ca, 12288, 47)
+    assert ca._early is not None and ca.near_fetch
+    assert int((ca.near_published_ids(0) >= 0).sum()) == 0
+    cb, _, _ = _headline_cache(8, False, L=12288, seed=47, max_length=16384)
+    kv_len = ca.sparse_end + 2
+    for step in range(3):
+        q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
+        oa = ca.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        ob = cb.select_fetch_attend_inplace(0, q, cs, kv_len=kv_len)
+        _gate_up_with_near_pull(ca, 0, gw)
+        torch.cuda.synchronize()
+        _check_staging_invariant(ca, 0)
+        assert torch.equal(oa.view(torch.int16), ob.view(torch.int16)), step
+        assert torch.equal(ca.v_cache_buffer.view(torch.int16), cb.v_cache_buffer.view(torch.int16)), step
 
 
 @pytest.mark.parametrize("kv_heads,glm,budget", [(8, False, 2048), (4, True, 2048), (8, False, 4096), (4, True, 4096), (8, False, 1024)])
@@ -742,7 +849,7 @@ def test_early_fetch_landmark_map_reproduces_the_slot_to_chunk_ids():
         torch.cuda.synchronize()
         st, o = cache._early["states"][0], cache._early["offsets"]
         B, N = cache.block_num, cache.k_landmark.shape[-2]
-        assert len(o) == 10
+        assert len(o) == 13
         gaps = st[o[8]:o[8] + 4 * B * 128].view(torch.int32).view(B, 128).cpu()
         ok = st[o[9]:o[9] + 4 * B].view(torch.int32).cpu()
         assert ok.tolist() == [1] * B
