@@ -115,7 +115,7 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
         # early fetch, 268.8 with it)
         model.kv_cache.enable_early_fetch(early_max=None if args.early_fetch < 0 else args.early_fetch, margin=args.early_margin,
-                                          near=bool(args.near_fetch) and args.batch == 1)
+                                          near=args.batch == 1 and (args.near_fetch == 1 or (args.near_fetch < 0 and model.kv_cache.num_key_value_groups <= 4)))
     torch.cuda.synchronize()
     return model, cfg, ctx, budget, time.perf_counter() - t0
 
@@ -913,10 +913,11 @@ def main(argv=None):
                     help="speculative early V fetch (bs 1, V table in host memory): chunks per head pulled beside normalise + "
                          "top-k; -1 = the default for the shape (32 for G <= 4, 64 for G = 8 at budget 2048, scaled with the budget: kv_cache.enable_early_fetch), 0 = off")
     ap.add_argument("--early-margin", type=float, default=0.0, help="added to the early fetch's logit thresholds")
-    ap.add_argument("--near-fetch", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--near-fetch", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the gate/up GEMV launch of every layer also stages the chunks that fell just short of the step's selection "
-                         "for the NEXT step (near misses: a third of them are selected next); needs the early fetch and the fused "
-                         "selection; identical results")
+                         "for the NEXT step (near misses: a third of them are selected next; profiles/r05_near_fetch.txt: +2-3 %% on "
+                         "the 8-KV-head shapes, nothing on the 4-KV-head ones); needs the early fetch and the fused selection; "
+                         "identical results.  -1 (default): on for G <= 4 at one sequence per GPU")
     ap.add_argument("--early-fetch-batches", type=int, default=0, choices=[0, 1],
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "
                          "off by default: measured 595.3 vs 594.9 tokens/s at bs 8, 769.3 vs 761.0 at bs 24 - the selection is a small "
@@ -1071,9 +1072,21 @@ def main(argv=None):
                     stats = cache.early_fetch_stats(model.num_layers - 1)
                 except Exception as e:
                     print(f"[bench] early-fetch statistics failed: {e}", file=sys.stderr)
+                near_rec = None
+                if cache.near_fetch:       # the same captured run with the in-step early fetch alone (no near-miss staging)
+                    cache.near_fetch = False
+                    rn = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                    cache.near_fetch = True
+                    near_rec = dict(slots_per_head=64, pull_workgroups_per_head=cache.near_pull_args(0)[-1],
+                                    value_without=dict(value=round(rn["value"], 2), ms_per_step=round(rn["ms_per_step"], 4), steps=short["steps"]),
+                                    note="near-miss staging ahead of the next step (round 5, csrc/skv_early.h skv_near_pull_role): the gate/up "
+                                         "GEMV launch of every layer stages the chunks that fell just short of the step's selection; "
+                                         "identical results, chunk hit rate and resident policy untouched (profiles/r05_near_fetch.txt)")
                 cache._early = None
                 r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
                 cache._early = ea
+                if near_rec is not None:
+                    extras["near_fetch"] = near_rec
                 extras["early_fetch"] = dict(
                     chunks_per_head=ea["E"], margin=ea["margin"],
                     last_layer_one_step=None if stats is None else dict(pulled_early=stats[0], read_from_staging=stats[1], misses=stats[2]),
@@ -1100,6 +1113,7 @@ def main(argv=None):
                        "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
             "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
             "launch_mode": head["mode"], "early_fetch_chunks_per_head": None if full or cache._early is None else cache._early["E"],
+            "near_fetch": bool(not full and cache._early is not None and getattr(cache, "near_fetch", False)),
             "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
             "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa, "per_rank": per_rank,
             "parity_note": "selection path bit-exact against the CPU oracle; top-k stage pinned to the reference's torch.topk "

@@ -391,9 +391,11 @@ SKV_EXPORT int skv_select_chunks_fused(const void* q, const void* landmarks, con
  * [B][G][2], 2 flag counts i32 [B][T], 3 flagged slots i32 [B][T][16], 4 pulled count i32 [B], 5 pulled chunk ids i32
  * [B][early_max], 6 staging index per chunk i16 [B][n_chunks], 7 staging [B][early_max][2048 B] - EIGHT entries.
  * skv_early_state_offsets2 writes the first n_out (<= SKV_EARLY_STATE_REGIONS) entries: 8, 9 see skv_early_state_set_landmark_map;
- * 10 near-miss count i32 [B], 11 near-miss list i32 [B][SKV_NEAR_SLOTS], 12 near misses staged now i32 [B][SKV_NEAR_SLOTS] (round 5:
+ * 10 near-miss count i32 [B], 11 near-miss list i32 [B][64], 12 near misses staged now i32 [B][SKV_NEAR_SLOTS] (round 5:
  * region 7, the staging, holds early_max + SKV_NEAR_SLOTS slots per (batch, head); see skv_norm_gemv_near_pull_bf16). */
+#ifndef SKV_NEAR_SLOTS
 #define SKV_NEAR_SLOTS 64
+#endif
 #define SKV_EARLY_STATE_REGIONS 13
 SKV_EXPORT size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chunks, int early_max);
 SKV_EXPORT int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out8);
@@ -482,18 +484,19 @@ SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride,
                             int64_t* hit_accum, skv_stream_t stream);
 
 /* Round 5, near-miss staging ahead of the NEXT decode step: skv_norm_gemv_bf16 with fuse_silu_mul = 1 (the gate/up launch of a
- * layer: residual add + RMSNorm + [gate; up] projection + SiLU * mul, K == 4096) whose first `blocks` workgroups do not compute
+ * layer: residual add + RMSNorm + [gate; up] projection + SiLU * mul, K == 4096) whose first `blocks` x pull_parts workgroups do not compute
  * but stage up to SKV_NEAR_SLOTS chunks per (batch, head) that fell just short of this step's selection - left in the early
  * state by the skv_select_chunks_fused call of the same step and layer - from the pinned host V table into staging slots
  * early_max .. early_max + SKV_NEAR_SLOTS - 1, publishing them in the state's chunk -> staging map.  The *_early fetch launch of
  * the NEXT step reads such a chunk from HBM instead of the host.  Same GEMV result as skv_norm_gemv_bf16, same cache bytes as
  * without it (staged bytes are host-table bytes); no extra launch, no extra stream.  early_state / blocks / groups /
  * n_landmarks / n_chunks / early_max as in skv_early_state_init; v_host / host_block_stride (elements per (batch, head)) as in
- * skv_select_chunks_fused. */
+ * skv_select_chunks_fused.  pull_parts (1, 2 or 4): pull workgroups per (batch, head) - chunk c belongs to part c % pull_parts,
+ * which owns SKV_NEAR_SLOTS / pull_parts of the slots; about 8 workgroups in all is what hides behind the GEMV (8 KV heads: 1). */
 SKV_EXPORT int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
                                             void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
                                             int n_landmarks, int n_chunks, int early_max, const void* v_host,
-                                            long long host_block_stride, skv_stream_t stream);
+                                            long long host_block_stride, int pull_parts, skv_stream_t stream);
 /* The lm_head and the sampler without streaming the logit row through one CU (round 4): skv_norm_gemv_rangemax_bf16 is
  * skv_norm_gemv_bf16 (no fused SiLU) that ALSO leaves, per 16 consecutive outputs, the largest one as an order-preserving
  * 16-bit key (bf16 x >= 0: x | 0x8000; x < 0: ~x) in range_max[N / 16] (N % 16 == 0); skv_sample_topk_advance_ranges is

@@ -322,7 +322,7 @@ int skv_early_state_offsets(int blocks, int groups, int n_landmarks, int n_chunk
 }
 
 // the first n_out (<= SKV_EARLY_STATE_REGIONS = 13) entries: 8 = the slot -> chunk-id gap table i32 [B][128], 9 = its validity flag,
-// 10 = near-miss count i32 [B], 11 = near-miss list i32 [B][64], 12 = near misses staged now i32 [B][64] (slots E .. E + 63 of 7)
+// 10 = near-miss count i32 [B], 11 = near-miss list i32 [B][64], 12 = near misses staged now i32 [B][96] (slots E .. E + 95 of 7)
 int skv_early_state_offsets2(int blocks, int groups, int n_landmarks, int n_chunks, int early_max, long long* out, int n_out) {
     return early_offsets(blocks, groups, n_landmarks, n_chunks, early_max, out, n_out);
 }
@@ -460,7 +460,7 @@ int skv_fetch_kv_early(const void* U, const void* SV, const void* cos_sin, const
     if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
-    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX};   // (slots [E, E + NEAR): near misses)
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_SLOTS};   // (slots [E, E + NEAR): near misses)
     return finish(skv_launch_rebuild(U, SV, cos_sin, chunk_ids, 1, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, k_temp, offsets, nullptr, v_host, v_cache, v_temp,
@@ -573,7 +573,7 @@ int skv_fetch_kv_inplace_early(const void* U, const void* SV, const void* cos_si
     if (!early_state || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1) return SKV_ERR_ARG;
     if (rope_mode != 1 && rope_mode != 2) return SKV_ERR_ARG;
     const EarlyState es = skv_carve_early((void*)early_state, batch_size * heads, groups, n_landmarks, n_chunks, early_max);
-    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX};   // (slots [E, E + NEAR): near misses)
+    const EarlyConsume ec{es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_SLOTS};   // (slots [E, E + NEAR): near misses)
     return finish(skv_launch_rebuild(U, SV, cos_sin, miss_ids, 0, cnts, k_cache, batch_size, heads, seq_len, head_dim,
                                      rank, select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h,
                                      cache_stride_s, sparse_start, rope_mode, nullptr, miss_ids, dst_slots, v_host,
@@ -632,7 +632,7 @@ int skv_fetch_kv_attn_inplace_early(const void* U, const void* SV, const void* c
                                       kv_len_dev, kv_len, kv_rows, batch_size, heads, q_heads, seq_len, head_dim, rank,
                                       select_sets, chunk_size, cos_sin_stride, cache_stride_b, cache_stride_h, cache_stride_s,
                                       sparse_start, rope_mode, host_block_stride, attn_splits, resident_sets, scale, stream,
-                                      es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_MAX);
+                                      es.early_of, es.staging, n_chunks, early_max + SKV_NEAR_SLOTS);
 }
 
 int skv_attn_finish_inplace(const void* attn_workspace, const int32_t* cnts, void* out, int batch_size, int q_heads,

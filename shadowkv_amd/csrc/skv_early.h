@@ -106,7 +106,7 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
     // chunks staged AHEAD of this step (near misses of the previous one, skv_near_pull_role) count as resident here: their
     // bytes are in staging already and early_of names them - flagging them again would pull them twice
-    const int my_near = (eh.near_pub != nullptr && tid < SKV_NEAR_MAX) ? eh.near_pub[(size_t)b * SKV_NEAR_MAX + tid] : -1;
+    const int my_near = (eh.near_pub != nullptr && tid < SKV_NEAR_SLOTS) ? eh.near_pub[(size_t)b * SKV_NEAR_SLOTS + tid] : -1;
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
     // (only an entry that still names this slot: the chunk may have been staged AHEAD since - skv_near_pull_role publishes it under
     // a slot >= E - and that entry must survive; the load is one more request of this round trip, the store follows it)
@@ -259,84 +259,98 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
 // Near-miss staging for the NEXT step (round 5).  The link idles during the 79 us of dense GEMVs of a
 // layer; which chunks the next step will miss is not known yet, but a third of the chunks that fell just short of THIS
 // step's selection are selected next (tools/near_miss_sim.py, bench workload: 64 nearest -> 19.5 of the ~83 misses per head).
-// One workgroup of 256 threads per (batch, head), riding as the FIRST workgroups of the layer's gate/up GEMV launch (no
-// extra launch or stream - the form that lost 13 % in round 3): it reconciles the new near-miss list (near_ids, from this
-// step's top-k launch) with what staging slots E .. E + 63 hold (near_pub), keeps what is in both, and pulls the rest from the
-// pinned host table into the slots of chunks that dropped out of the list.  early_of[chunk] = E + slot is the same map the
-// in-step early fetch publishes in, so the fetch launch of the next step finds these chunks with the lookup it does anyway,
-// and the in-step list leaves them alone (they are in its resident bitmap).
+// `parts` (1, 2 or 4) workgroups of 256 threads per (batch, head), riding as the FIRST workgroups of the layer's gate/up GEMV
+// launch (no extra launch or stream - the form that lost 13 % in round 3).  Part p owns the chunks with id % parts == p and the
+// staging slots E + p * 64 / parts .. : it reconciles its share of the new near-miss list (near_ids, from this
+// step's top-k launch) with what its slots hold (near_pub), keeps what is in both, and pulls the rest from the pinned host
+// table into the slots of chunks that dropped out of the list - independent of the other parts (no workgroup reads state
+// another one writes in the same launch).  One workgroup per head pulling slowly is the form that pays (skv_launch.h): the
+// harder the role pulls, the more the HBM-bound GEMV beside it loses.  early_of[chunk] = E + slot is the map
+// the in-step early fetch publishes in too, so the fetch launch of the next step finds these chunks with the lookup it does
+// anyway, and the in-step list leaves them alone (they are in its resident bitmap).
 // Nothing here can change a result: a staging slot is published (near_pub, early_of) only with the host table's bytes of
 // the chunk it names; a chunk's old entry is cleared before its slot is overwritten, both by this workgroup, in this order,
 // behind a barrier; everything is consumed by LATER launches.  An entry is only cleared if it still names this slot.
-// smem: 4 * SKV_NEAR_MAX + 8 ints.
+// smem: 4 * 64 + 8 ints.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int b, int tid, int* smem) {
-    constexpr int P = SKV_NEAR_MAX;
-    static_assert(P == 64, "one wave reconciles the lists with 64-bit ballots");
-    int* const s_old = smem;            // [P] staged now
-    int* const s_new = smem + P;        // [P] this step's near misses (-1 beyond the count)
-    int* const s_slot = smem + 2 * P;   // [P] slot of the i-th chunk to pull
-    int* const s_id = smem + 3 * P;     // [P] its id
-    int* const s_n = smem + 4 * P;      // [1] chunks to pull
+#ifndef SKV_NEAR_INFLIGHT
+#define SKV_NEAR_INFLIGHT 16       // 16-B requests a thread of the pull role keeps in flight (32: 188 VGPRs - a GEMV wave per SIMD less)
+#endif
+__device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, int tid, int* smem) {
+    constexpr int NL = SKV_NEAR_MAX;
+    static_assert(NL == 64 && SKV_NEAR_SLOTS == 64, "one wave reconciles: the list and a part's slots in 64-bit ballots");
+    const int PARTS = np.parts, PS = SKV_NEAR_SLOTS / PARTS;               // (parts in {1, 2, 4}: checked by the launcher)
+    const int b = blk / PARTS, part = blk % PARTS;
+    int* const s_new = smem;              // [NL] this step's near misses of this part (-1: none / another part's)
+    int* const s_old = smem + NL;         // [<= 64] staged now in this part's slots
+    int* const s_slot = s_old + 64;       // [<= 64] local slot of the i-th chunk to pull
+    int* const s_id = s_slot + 64;        // [<= 64] its id
+    int* const s_n = s_id + 64;           // [1] chunks to pull
     const int n_chunks = np.n_chunks, E = np.E;
-    if (tid < P) {
-        const int cnt = min(max(np.near_cnt[b], 0), P);
-        const int o = np.near_pub[(size_t)b * P + tid];
-        int n = tid < cnt ? np.near_ids[(size_t)b * P + tid] : -1;
-        if (n < 0 || n >= n_chunks) n = -1;
-        s_old[tid] = (o >= 0 && o < n_chunks) ? o : -1;
+    const int slot0 = part * PS;          // first near slot of this part
+    if (tid < NL) {
+        const int cnt = min(max(np.near_cnt[b], 0), NL);
+        int n = tid < cnt ? np.near_ids[(size_t)b * NL + tid] : -1;
+        if (n < 0 || n >= n_chunks || n % PARTS != part) n = -1;
         s_new[tid] = n;
+        if (tid < PS) {
+            const int o = np.near_pub[(size_t)b * SKV_NEAR_SLOTS + slot0 + tid];
+            s_old[tid] = (o >= 0 && o < n_chunks) ? o : -1;
+        }
     }
     __syncthreads();
-    if (tid < P) {                      // wave 0
-        const int o = s_old[tid], n = s_new[tid];
+    if (tid < NL) {                       // wave 0
+        const int n = s_new[tid], o = tid < PS ? s_old[tid] : -1;
         bool keep = false, fresh = n >= 0;
 #pragma unroll 8
-        for (int i = 0; i < P; ++i) {
+        for (int i = 0; i < NL; ++i) {
             keep |= o >= 0 && s_new[i] == o;
-            fresh &= s_old[i] != n;
             if (i < tid) fresh &= s_new[i] != n;          // (the list holds distinct ids; a duplicate would be staged once)
         }
-        const unsigned long long free_m = ~__ballot(keep);            // slots whose chunk left the list (or empty)
+        for (int j = 0; j < PS; ++j) fresh &= s_old[j] != n;
+        const unsigned long long slots_m = PS >= 64 ? ~0ull : ((1ull << (PS & 63)) - 1ull);
+        const unsigned long long free_m = ~__ballot(tid < PS && keep) & slots_m;   // slots whose chunk left the list (or empty)
         const unsigned long long fresh_m = __ballot(fresh);
-        const int n_fresh = __builtin_popcountll(fresh_m);            // <= popcount(free_m): |new| <= P
+        const int n_take = min(__builtin_popcountll(fresh_m), __builtin_popcountll(free_m));   // (the list's tail waits when slots are short)
         if (fresh) {
-            int k = __builtin_popcountll(fresh_m & ((1ull << tid) - 1ull));
-            unsigned long long m = free_m;                             // the k-th free slot
-            for (int i = 0; i < k; ++i) m &= m - 1;
-            const int e = __builtin_ctzll(m);
-            s_slot[k] = e;
-            s_id[k] = n;
-            const int old = s_old[e];
-            // the slot's old chunk: unpublished before its bytes are overwritten (only if the entry still names this slot)
-            if (old >= 0 && np.early_of[(size_t)b * n_chunks + old] == (short)(E + e)) np.early_of[(size_t)b * n_chunks + old] = (short)-1;
+            const int k = __builtin_popcountll(fresh_m & ((1ull << tid) - 1ull));
+            if (k < n_take) {
+                unsigned long long m = free_m;                             // the k-th free slot
+                for (int i = 0; i < k; ++i) m &= m - 1;
+                const int e = __builtin_ctzll(m);
+                s_slot[k] = e;
+                s_id[k] = n;
+                const int old = s_old[e];
+                // the slot's old chunk: unpublished before its bytes are overwritten (only if the entry still names this slot)
+                if (old >= 0 && np.early_of[(size_t)b * n_chunks + old] == (short)(E + slot0 + e))
+                    np.early_of[(size_t)b * n_chunks + old] = (short)-1;
+            }
         }
-        if (tid == 0) s_n[0] = n_fresh;
+        if (tid == 0) s_n[0] = n_take;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n_pull = s_n[0];
     const u32x4* const hb = reinterpret_cast<const u32x4*>(np.v_host) + (long long)b * np.v_host_stride_u128;
-    u32x4* const sb = reinterpret_cast<u32x4*>(np.staging) + ((size_t)b * (E + P) + E) * 128;
-    // chunk = 128 units of 16 B; 256 threads: two chunks per pass, 8 requests per thread in flight (unconditional loads through
-    // a selected pointer, as in skv_early_pull_role)
-    for (int r0 = 0; r0 * 256 < n_pull * 128; r0 += 8) {
-        u32x4 v[8];
-        int dst[8];
+    u32x4* const sb = reinterpret_cast<u32x4*>(np.staging) + ((size_t)b * (E + SKV_NEAR_SLOTS) + E + slot0) * 128;
+    // chunk = 128 units of 16 B; 256 threads: two chunks per pass, SKV_NEAR_INFLIGHT requests per thread in flight
+    // (unconditional loads through a selected pointer, as in skv_early_pull_role)
+    for (int r0 = 0; r0 * 256 < n_pull * 128; r0 += SKV_NEAR_INFLIGHT) {
+        u32x4 v[SKV_NEAR_INFLIGHT];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < SKV_NEAR_INFLIGHT; ++k) {
             const int idx = (r0 + k) * 256 + tid, i = idx >> 7, u = idx & 127;
-            const bool on = i < n_pull;
-            dst[k] = on ? s_slot[i] * 128 + u : -1;
-            const u32x4* src = on ? hb + (long long)s_id[i] * 128 + u : reinterpret_cast<const u32x4*>(sb) + u;
+            const u32x4* src = i < n_pull ? hb + (long long)s_id[i] * 128 + u : reinterpret_cast<const u32x4*>(sb) + u;
             v[k] = *src;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (dst[k] >= 0) sb[dst[k]] = v[k];
+        for (int k = 0; k < SKV_NEAR_INFLIGHT; ++k) {
+            const int idx = (r0 + k) * 256 + tid, i = idx >> 7, u = idx & 127;
+            if (i < n_pull) sb[s_slot[i] * 128 + u] = v[k];
+        }
     }
-    if (tid < n_pull) {                 // publish (read by later launches only)
-        np.near_pub[(size_t)b * P + s_slot[tid]] = s_id[tid];
-        np.early_of[(size_t)b * n_chunks + s_id[tid]] = (short)(E + s_slot[tid]);
+    if (tid < n_pull) {                   // publish (read by later launches only)
+        np.near_pub[(size_t)b * SKV_NEAR_SLOTS + slot0 + s_slot[tid]] = s_id[tid];
+        np.early_of[(size_t)b * n_chunks + s_id[tid]] = (short)(E + slot0 + s_slot[tid]);
     }
 }

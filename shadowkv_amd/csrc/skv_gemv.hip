@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     int bx = blockIdx.x;
     if constexpr (NEARP) {
         if (bx < np.blocks) {
-            __shared__ int s_near[4 * SKV_NEAR_MAX + 8];
+            __shared__ int s_near[4 * 64 + 8];
             skv_near_pull_role(np, bx, threadIdx.x, s_near);
             return;
         }
@@ -295,7 +295,8 @@ static int launch_gemv(const void* W, const void* x, const void* bias, void* y, 
     if (K % 8 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
     if (near) {          // the gate/up launch of a layer with the near-miss pull role in front of its grid
-        if (!norm || !fuse_silu_mul || qkv || range_max || (N % 2) || bias || near->blocks < 1) return SKV_ERR_UNSUPPORTED;
+        if (!norm || !fuse_silu_mul || qkv || range_max || (N % 2) || bias || near->blocks < 1 || near->E + SKV_NEAR_SLOTS > 32767)
+            return SKV_ERR_UNSUPPORTED;
         const int I = N / 2, grid = (I + 7) / 8;
         hipLaunchKernelGGL((skv_gemv_kernel<4, true, true, false, false, true>), dim3(near->blocks + grid), dim3(256), 0, st,
                            (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, I, (const bf16_t*)residual,
@@ -359,13 +360,14 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
 extern "C" int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
                                             void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
                                             int n_landmarks, int n_chunks, int early_max, const void* v_host,
-                                            long long host_block_stride, skv_stream_t stream) {
+                                            long long host_block_stride, int pull_parts, skv_stream_t stream) {
+    if (pull_parts != 1 && pull_parts != 2 && pull_parts != 4) return SKV_ERR_ARG;
     if (!early_state || !v_host || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1 || early_max > 128 ||
         (host_block_stride % 8))
         return SKV_ERR_ARG;
     if (n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;      // (the early state's limit, skv_select_chunks_fused)
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    const NearPull np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max);
+    const NearPull np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max, pull_parts);
     return launch_gemv(W, x, nullptr, y, N, K, 1, residual, norm_weight, h_out, eps, true, (hipStream_t)stream, nullptr, nullptr, &np);
 }
 

@@ -82,12 +82,12 @@ struct EarlyHooks {
     const int* map_ok;          // [B]
     // near-miss staging for the NEXT step (round 5, see EarlyState): the top-k launch leaves up to SKV_NEAR_MAX chunk ids that
     // fell just short of this step's selection (near_ids / near_cnt, prediction only); the pull role of the gate/up GEMV
-    // launch stages them (skv_near_pull_role) and publishes them in early_of with staging indices E .. E + SKV_NEAR_MAX - 1;
+    // launch stages them (skv_near_pull_role) and publishes them in early_of with staging indices E .. E + SKV_NEAR_SLOTS - 1;
     // near_pub = the ids published there now (-1: slot unused) - the in-step list treats them like resident chunks.
     int* near_cnt;              // [B]
     int* near_ids;              // [B][SKV_NEAR_MAX]
-    const int* near_pub;        // [B][SKV_NEAR_MAX]
-    int stage_stride;           // staging slots per (batch, head): E + SKV_NEAR_MAX
+    const int* near_pub;        // [B][SKV_NEAR_SLOTS]
+    int stage_stride;           // staging slots per (batch, head): E + SKV_NEAR_SLOTS
 };
 
 // Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.
@@ -99,12 +99,18 @@ struct EarlyHooks {
 //   early_of  [B][chunks] i16 staging index of a chunk pulled early this step, -1 otherwise
 //   staging   [B][E][2 KiB]   the pulled V chunks
 //   near_cnt  [B] i32, near_ids [B][SKV_NEAR_MAX] i32   round 5: chunks just below this step's selection (written by the top-k
-//                              launch), candidates for staging ahead of the NEXT step; near_pub [B][SKV_NEAR_MAX] i32 the chunks
+//                              launch), candidates for staging ahead of the NEXT step; near_pub [B][SKV_NEAR_SLOTS] i32 the chunks
 //                              staged that way now: chunk near_pub[b][e] sits in staging slot E + e, early_of[chunk] = E + e
-//   staging is [B][E + SKV_NEAR_MAX][2 KiB]: slots [0, E) belong to the in-step early fetch, [E, E + SKV_NEAR_MAX) to the near misses
+//   staging is [B][E + SKV_NEAR_SLOTS][2 KiB]: slots [0, E) belong to the in-step early fetch, [E, E + SKV_NEAR_SLOTS) to the near misses
 #define SKV_EARLY_K 16
 #define SKV_EARLY_GAPS 128     // chunks that may be missing from a head's ascending landmark-id sequence (outliers: 24 per 1024 budget)
-#define SKV_NEAR_MAX 64        // near-miss staging slots per (batch, head)
+#define SKV_NEAR_MAX 64        // near misses the top-k launch lists per (batch, head)
+// near-miss staging slots per (batch, head).  The gate/up launch's pull role runs `parts` (1, 2 or 4, a launch argument)
+// workgroups per (batch, head): part p owns the chunks with id % parts == p and the slots [p * SLOTS / parts, (p + 1) * SLOTS / parts).
+// Measured on MI355X, tokens/s with / without the role on one box (profiles/r05_near_fetch.txt):
+//   8 KV heads (Llama-3.1-8B 122K): 1 part, 16 requests per thread in flight: 233.9 / 226.9 (+3.0 %); 4 parts: 227.3 / 226.7 (+0.3 %)
+// - the role costs the HBM-bound GEMV it rides in more the harder it pulls: a slow trickle from ~8 CUs is what hides.
+#define SKV_NEAR_SLOTS 64
 struct EarlyState {
     float* dthr;
     float* finals;
@@ -134,12 +140,12 @@ static inline EarlyState skv_carve_early(void* base, int B, int G, int n_landmar
     e.early_cnt = (int*)(p + off);   off += skv_early_align((size_t)B * 4);
     e.early_ids = (int*)(p + off);   off += skv_early_align((size_t)B * E * 4);
     e.early_of = (short*)(p + off);  off += skv_early_align((size_t)B * n_chunks * 2);
-    e.staging = p + off;             off += skv_early_align((size_t)B * (E + SKV_NEAR_MAX) * 2048);
+    e.staging = p + off;             off += skv_early_align((size_t)B * (E + SKV_NEAR_SLOTS) * 2048);
     e.gap_slots = (int*)(p + off);   off += skv_early_align((size_t)B * SKV_EARLY_GAPS * 4);
     e.map_ok = (int*)(p + off);      off += skv_early_align((size_t)B * 4);
     e.near_cnt = (int*)(p + off);    off += skv_early_align((size_t)B * 4);
     e.near_ids = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_MAX * 4);
-    e.near_pub = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_MAX * 4);
+    e.near_pub = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_SLOTS * 4);
     e.total = off;
     return e;
 }
@@ -155,7 +161,7 @@ static inline EarlyHooks skv_early_hooks(const EarlyState& es, int groups, float
     eh.near_cnt = es.near_cnt;
     eh.near_ids = es.near_ids;
     eh.near_pub = es.near_pub;
-    eh.stage_stride = E + SKV_NEAR_MAX;
+    eh.stage_stride = E + SKV_NEAR_SLOTS;
     return eh;
 }
 
@@ -164,14 +170,15 @@ static inline EarlyHooks skv_early_hooks(const EarlyState& es, int groups, float
 struct NearPull {
     const int* near_cnt;        // [B]   (top-k launch of this step)
     const int* near_ids;        // [B][SKV_NEAR_MAX]
-    int* near_pub;              // [B][SKV_NEAR_MAX] in / out: what staging slots E .. hold
+    int* near_pub;              // [B][SKV_NEAR_SLOTS] in / out: what staging slots E .. hold
     short* early_of;            // [B][n_chunks]
-    void* staging;              // [B][E + SKV_NEAR_MAX][2 KiB]
+    void* staging;              // [B][E + SKV_NEAR_SLOTS][2 KiB]
     const void* v_host;
     long long v_host_stride_u128;
-    int blocks;                 // B = batch x KV heads: one pull workgroup each
-    int n_chunks, E;
+    int blocks;                 // B * parts pull workgroups (B = batch x KV heads)
+    int n_chunks, E, parts;
 };
-static inline NearPull skv_near_pull(const EarlyState& es, const void* v_host, long long host_block_stride, int B, int n_chunks, int E) {
-    return NearPull{es.near_cnt, es.near_ids, es.near_pub, es.early_of, es.staging, v_host, host_block_stride / 8, B, n_chunks, E};
+static inline NearPull skv_near_pull(const EarlyState& es, const void* v_host, long long host_block_stride, int B, int n_chunks, int E,
+                                     int parts) {
+    return NearPull{es.near_cnt, es.near_ids, es.near_pub, es.early_of, es.staging, v_host, host_block_stride / 8, B * parts, n_chunks, E, parts};
 }

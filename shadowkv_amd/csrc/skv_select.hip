@@ -1010,7 +1010,10 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
         TOPK_STAMP(16);
 #endif
         int thr, need_eq;
-        t2_find_threshold<1>(w2, 2 * T2_THREADS - C, S, tid, s_hist, s_w, s_out, thr, need_eq, [] {});
+        // (with the early state: also the (S + SKV_NEAR_MAX)-th candidate score - the near misses below are the candidates between the two)
+        int thr_near = 0;
+        t2_find_threshold<1>(w2, 2 * T2_THREADS - C, S, tid, s_hist, s_w, s_out, thr, need_eq, [] {},
+                             eh.near_ids != nullptr ? S + SKV_NEAR_MAX : 0, &thr_near);
         TOPK_STAMP(17);
         if (thr >= 0x0100) {                                     // a normal bf16 number: the strictness argument holds
             if (eh.dthr_out != nullptr && tid < FG) {            // next step's flag thresholds (early fetch; prediction only)
@@ -1049,10 +1052,12 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             if (eh.near_ids != nullptr) {
                 // Near misses (round 5; prediction only, nothing downstream of the selection reads it): the candidates that were
                 // evaluated exactly and fell short of the S-th score are the chunks most likely to enter the NEXT step's selection
-                // (tools/near_miss_sim.py: a third of the 64 nearest do).  The first SKV_NEAR_MAX of them in slot order go to
-                // near_ids; the gate/up GEMV launch of this layer stages them while the link is idle (skv_near_pull_role).
-                // One more block scan: the selection workgroup finishes microseconds before the launch's pull workgroups.
-                const int la = va && lo < thr, lb = vb && hi < thr;
+                // (tools/near_miss_sim.py: a third of the 64 nearest do).  The candidates from the S-th score down to the
+                // (S + SKV_NEAR_MAX)-th (thr_near; 0 = all of them when that score is outside the histogram window), the first
+                // SKV_NEAR_MAX in slot order, go to near_ids; the gate/up GEMV launch of this layer stages them while the link is
+                // idle (skv_near_pull_role).  One more block scan: the selection workgroup finishes microseconds before the
+                // launch's pull workgroups.
+                const int la = va && lo < thr && lo >= thr_near, lb = vb && hi < thr && hi >= thr_near;
                 const int nincl = block_scan_incl1(la + lb, searched ? s_w + 48 : s_w + 32, tid);   // (the row the last scan did not use)
                 int npos = nincl - (la + lb);
                 if (la) {

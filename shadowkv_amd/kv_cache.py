@@ -270,6 +270,7 @@ class ShadowKVCache_CPU:
         # launch of every layer stages the chunks that fell just short of this step's selection (near_pull_args ->
         # tensor_op.norm_linear_decode(near_pull=)); the next step's fetch launch reads them from HBM.  Identical results.
         self.near_fetch = False
+        self.near_pull_parts = None      # pull workgroups per (batch, head): None = about 8 in all (1 for 8 KV heads, 2 for 4)
         self._copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -878,16 +879,17 @@ class ShadowKVCache_CPU:
     def near_pull_args(self, layer_idx):
         """Arguments of tensor_op.norm_linear_decode(..., near_pull=) for this layer's gate/up launch, or None when the
         near-miss staging is off (`near_fetch`, enable_early_fetch(near=True)): (early state, blocks, groups, landmarks,
-        chunks, early_max, V table, its per-head stride)."""
+        chunks, early_max, V table, its per-head stride, pull workgroups per head)."""
         ea = self._early
         if ea is None or not self.near_fetch or not self.fused_select or self._sel_state is None:
             return None
         vhost = self.v_cache_cpu[layer_idx]
         return (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],
-                ptr(vhost), vhost.stride(1))
+                ptr(vhost), vhost.stride(1), self.near_pull_parts or max(1, min(4, 8 // ea["blocks"])))
 
     def near_published_ids(self, layer_idx):
-        """int32 [blocks, 64]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 63; -1 = empty."""
+        """int32 [blocks, 64]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 63
+        (SKV_NEAR_SLOTS); -1 = empty."""
         e = self._early
         o, B = e["offsets"], self.block_num
         return e["states"][layer_idx][o[12]:o[12] + 4 * B * 64].view(torch.int32).view(B, 64).cpu()
