@@ -650,7 +650,7 @@ def measure_fetch_launch(model, ctx, walk_step, steps=3, seed=31):
                     steps, "" if early is None else " (early fetch off for this measurement: all miss bytes cross the link inside the launch)"))
 
 
-def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inplace=False):
+def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inplace=False, reference_calls=False):
     """The drop-in path: DecoderLM.decode_step(fused=False) = the reference's call order (inference -> layer_compute:
     pre_attention_compute, apply_rotary_pos_emb, update_kv_cache, get_retrieval_position_ids, get_value_cache under
     copy_stream || get_key_cache, attention, post_attention_compute; models/base.py:315-341, models/llama.py:354-427),
@@ -665,6 +665,7 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inpl
     lazy_before, inplace_before = cache.lazy_value_fetch, cache.inplace_methods
     cache.lazy_value_fetch = bool(lazy_v)
     cache.inplace_methods = bool(inplace and lazy_v)
+    cache.reference_calls = bool(reference_calls)      # (the reference's own launch sequence through the twelve names)
     try:
         def step():
             nonlocal tok
@@ -684,9 +685,11 @@ def run_call_order(model, ctx, steps, warmup, walk_step, seed, lazy_v=True, inpl
     finally:
         model.query_hook = None
         cache.lazy_value_fetch, cache.inplace_methods = lazy_before, inplace_before
+        cache.reference_calls = False
         rewind(model, ctx)
     return dict(value=round(steps * model.batch_size / dt, 2), ms_per_step=round(dt / steps * 1e3, 4),
-                chunk_hit_rate=round((float(hits) - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets), 4),
+                chunk_hit_rate=None if reference_calls else      # (that mode shares ONE counts tensor between the layers, as the reference does)
+                round((float(hits) - h0) / (steps * model.num_layers * cache.block_num * cache.select_sets), 4),
                 steps=steps, warmup=warmup, launch_mode="eager", lazy_value_fetch=bool(lazy_v), inplace_methods=bool(inplace and lazy_v),
                 note="decode_step(fused=False): reference call order through layer_compute / copy_stream / the "
                      "reference-shaped cache methods (what INTEGRATION.md's three changed imports run)"
@@ -1034,6 +1037,15 @@ def main(argv=None):
                     value=inpl["value"], ms_per_step=inpl["ms_per_step"],
                     note="kv_cache.inplace_methods: the same calls on the in-place layout (no staging launch for moved hits; same "
                          "chunk sets, slot order differs from the reference's)")
+                refc = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False,
+                                      reference_calls=True)
+                extras["value_call_order"]["reference_launch_sequence"] = dict(
+                    value=refc["value"], ms_per_step=refc["ms_per_step"],
+                    note="kv_cache.reference_calls: the reference's OWN launch sequence across the native boundary (kv_cache.py:983-1176: "
+                         "batch_gemm_softmax -> torch.max / topk / gather -> reorder_keys_and_compute_offsets -> gather_copy_with_offsets -> "
+                         "gather_copy_d2d_with_offsets -> batch_gather_gemm -> apply_rotary_pos_emb_push_cache_opt) through the twelve "
+                         "kernels.shadowkv names - what swapping only the native module under the reference's Python gives; pinned call "
+                         "by call to a recording of the reference (tests/test_decode_trace.py)")
                 if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
                     r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
                                    seed=99 + rank)

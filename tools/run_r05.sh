@@ -11,3 +11,4 @@ timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_benc
 python tools/show_bench.py gpurun_out/${tag}_bench.json 2>/dev/null | cut -c1-400
 tools/prof.sh ${tag} --steps 24 --warmup 6 | cut -c1-170 || exit 1
 tools/prof.sh ${tag}_glm --workload glm4_200k --steps 16 --warmup 6 | cut -c1-170 || exit 1
+tools/pmc_score.sh ${tag} | tail -24
