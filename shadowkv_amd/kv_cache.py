@@ -528,6 +528,7 @@ class ShadowKVCache_CPU:
                                             ptr(vhost), vhost.stride(1), 0 if ea is None else ea["n_chunks"],
                                             0 if ea is None else ea["E"], 0.0 if ea is None else ea["margin"], st),
                   "select_chunks_fused")
+            self._near_listed = layer_idx if ea is not None else -1      # (this launch left the layer's near-miss list)
             return ea is not None
         if inplace:
             sel_args = (ptr(q), ptr(lm), ptr(lv.lm_idx), ptr(lv.pos), ptr(self.offsets), ptr(self._dst_slots), ptr(self.cnts),
@@ -882,6 +883,8 @@ class ShadowKVCache_CPU:
         chunks, early_max, V table, its per-head stride, pull workgroups per head)."""
         ea = self._early
         if ea is None or not self.near_fetch or not self.fused_select or self._sel_state is None:
+            return None
+        if getattr(self, "_near_listed", -1) != layer_idx:       # this step's selection of the layer ran without the early state
             return None
         vhost = self.v_cache_cpu[layer_idx]
         return (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],

@@ -113,6 +113,8 @@ class DecoderLM:
         self.norm_weight = torch.ones(cfg.hidden_size, device=self.device, dtype=dtype)
         self.norm_variance_epsilon = cfg.rms_norm_eps
         self.layers = [DecoderLayer(cfg, self.device, dtype, gen) for _ in range(self.num_layers)]
+        for i, lay in enumerate(self.layers):
+            lay.layer_idx = i            # (post_attention_compute has the reference's signature: the layer object only)
         # RoPE rows for the context plus every position decode can reach (the kernels index it with the device-side
         # position counter: it must never run past the table)
         self.max_new_tokens = int(max_new_tokens)
@@ -251,9 +253,14 @@ class DecoderLM:
             sc = self._decode_scratch(attn_output.shape[0])
             cur = sc["sets"][sc["i"]]
             o = tensor_op.linear_decode(attn_output, layer.wo, out=cur["o"])
+            # (one sequence on the ShadowKV cache with near_fetch: the launch's first workgroups stage this step's near misses)
+            near = None
+            if attn_output.shape[0] == 1 and self.attn_mode != "full" and getattr(layer, "layer_idx", None) is not None:
+                near = self.kv_cache.near_pull_args(layer.layer_idx)
             residual, act = tensor_op.norm_linear_decode(o, residual, layer.post_attention_layernorm_weight,
                                                          layer.post_attention_layernorm_variance_epsilon,
-                                                         layer.gate_up_proj, fuse_silu_mul=True, out=cur["act"], h_out=cur["h"])
+                                                         layer.gate_up_proj, fuse_silu_mul=True, out=cur["act"], h_out=cur["h"],
+                                                         near_pull=near)
             if residual.shape[0] == 1:      # one sequence: the residual rides in the GEMV's bias slot (bf16(W.act) + residual,
                 #                             rounded like the separate add: same bits, one launch less)
                 return tensor_op.linear_decode(act, layer.down_proj, bias=residual, out=cur["out"])

@@ -260,20 +260,20 @@ def test_captured_default_path_against_the_oracle_at_full_size(shape):
 @pytest.mark.parametrize("cfg_name,glm", [("LLAMA_3_1_8B", False), ("GLM_4_9B_1M", True)])
 def test_ninety_steps_agree_across_all_selection_paths(cfg_name, glm):
     """Soak: 90 captured steps (the generated-row slack allows 96) of one prompt through the four selection paths - fused
-    selection with / without the early fetch, three-launch selection with / without it - on the same query walk: sampled
+    selection with / without the early fetch (and with the round-5 near-miss staging on top), three-launch selection with / without it - on the same query walk: sampled
     tokens of every step, the final slot -> chunk map, hit counts and both caches bit for bit.  Covers what a 6-step run does
     not: the witness-level controller of the fused selection over many steps, early-fetch
     staging slots being reused dozens of times, and the generated rows filling up."""
     from shadowkv_amd import llama
     ctx, steps = 32768, 90
     runs = {}
-    for fused, early in ((True, True), (True, False), (False, True), (False, False)):
+    for fused, early in ((True, "near"), (True, True), (True, False), (False, True), (False, False)):
         m = llama.DecoderLM(cfg=getattr(llama, cfg_name), batch_size=1, max_length=ctx, device=DEV, sparse_budget=2048, rank=160,
                             chunk_size=8, num_layers=2, seed=3, chunk_layout="inplace", overlap_attention=True)
         llama.build_synthetic_context(m, ctx, seed=11)
         m.kv_cache.fused_select = fused
         if early:
-            m.kv_cache.enable_early_fetch()
+            m.kv_cache.enable_early_fetch(near=early == "near")     # ("near": + the near-miss staging in the gate/up launches, round 5)
         table = llama.make_walk_table(m, 16, seed=5)
         dec = llama.GraphDecoder(m, temperature=0.6, walk_table=table)
         dec.token.copy_(torch.tensor([[7]], device=DEV))
@@ -292,6 +292,8 @@ def test_ninety_steps_agree_across_all_selection_paths(cfg_name, glm):
             assert paths.count(0) > len(paths) // 2, (paths.count(0), len(paths))
         if early:
             assert pulled > 0
+        if early == "near":      # 64 slots per head reused over ~88 steps: the staged chunks are still what the map says
+            assert all(int((c.near_published_ids(l) >= 0).sum()) > 0 for l in range(m.num_layers))
         runs[(fused, early)] = (toks, c.position_ids.clone(), c._cnts_layers.clone(), c.k_cache_buffer.view(torch.int16).clone(),
                                 c.v_cache_buffer.view(torch.int16).clone(), c.gen_offset)
         del dec, m

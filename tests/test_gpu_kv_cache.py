@@ -579,7 +579,7 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
     cb, _, _ = _headline_cache(kv_heads, glm, L=L, seed=41, budget=budget)
     ca.enable_early_fetch(near=True)
     cb.enable_early_fetch()
-    assert ca.near_pull_args(0) is not None and cb.near_pull_args(0) is None
+    assert ca.near_pull_args(0) is None and cb.near_pull_args(0) is None      # (no selection has left a near-miss list yet)
     kv_len = ca.sparse_end + 2
     q = (torch.randn(1, 32, 1, 128, device=DEV, generator=g) * 1.5).bfloat16()
     gw = torch.Generator(device=DEV).manual_seed(3)
@@ -604,6 +604,7 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
         ins = ca._early_published_ids(0)
         for b in range(B):
             assert not (set(ins[b][ins[b] >= 0].tolist()) & before[b]), (step, b)
+        assert cb.near_pull_args(0) is None
         _gate_up_with_near_pull(ca, 0, gw)
         _check_staging_invariant(ca, 0)
         staged_total += int((ca.near_published_ids(0) >= 0).sum())
