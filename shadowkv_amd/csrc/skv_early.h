@@ -273,6 +273,9 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
 // behind a barrier; everything is consumed by LATER launches.  An entry is only cleared if it still names this slot.
 // smem: 4 * 64 + 8 ints.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef SKV_NEAR_PULL_CAP
+#define SKV_NEAR_PULL_CAP 32       // chunks one workgroup of the pull role stages per launch = ONE round of requests (the rest of the list waits a step; measured: 64 / 32 / 16 -> 230.9 / 231.7 / 228.3 tokens/s, 226.8 without the role)
+#endif
 #ifndef SKV_NEAR_INFLIGHT
 #define SKV_NEAR_INFLIGHT 16       // 16-B requests a thread of the pull role keeps in flight (32: 188 VGPRs - a GEMV wave per SIMD less)
 #endif
@@ -311,7 +314,7 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
         const unsigned long long slots_m = PS >= 64 ? ~0ull : ((1ull << (PS & 63)) - 1ull);
         const unsigned long long free_m = ~__ballot(tid < PS && keep) & slots_m;   // slots whose chunk left the list (or empty)
         const unsigned long long fresh_m = __ballot(fresh);
-        const int n_take = min(__builtin_popcountll(fresh_m), __builtin_popcountll(free_m));   // (the list's tail waits when slots are short)
+        const int n_take = min(min(__builtin_popcountll(fresh_m), __builtin_popcountll(free_m)), SKV_NEAR_PULL_CAP);   // (the list's tail waits)
         if (fresh) {
             const int k = __builtin_popcountll(fresh_m & ((1ull << tid) - 1ull));
             if (k < n_take) {

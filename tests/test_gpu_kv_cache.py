@@ -585,6 +585,7 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
     gw = torch.Generator(device=DEV).manual_seed(3)
     B, S = ca.block_num, ca.select_sets
     served = staged_total = 0
+    near_quality = []
     for step in range(8):
         q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
         before = [set(r[r >= 0].tolist()) for r in ca.near_published_ids(0)]        # staged ahead, as this step's fetch sees it
@@ -605,10 +606,34 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
         for b in range(B):
             assert not (set(ins[b][ins[b] >= 0].tolist()) & before[b]), (step, b)
         assert cb.near_pull_args(0) is None
+        # the near-miss list this step's top-k launch left: distinct landmark chunks that were NOT selected, none scoring above
+        # the S-th score, and (prediction quality, not a contract) mostly the ranks S + 1 .. S + 64 of the oracle's exact scores
+        o, st = ca._early["offsets"], ca._early["states"][0]
+        ncnt = st[o[10]:o[10] + 4 * B].view(torch.int32).cpu()
+        nids = st[o[11]:o[11] + 4 * B * 64].view(torch.int32).view(B, 64).cpu()
+        lm, lm_idx = ca.k_landmark[0][0].cpu().contiguous(), ca.k_landmark_idx[0][0].cpu()
+        N, Gq = lm.shape[1], 32 // kv_heads
+        Dm = torch.zeros(kv_heads, Gq, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
+        T = (N + 255) // 256
+        oracle.batch_gemm_softmax(q.cpu().view(kv_heads, Gq, 128).contiguous(), lm, Dm, torch.zeros(kv_heads, T, Gq),
+                                  torch.zeros(kv_heads, T, Gq), P, kv_heads, Gq, N, 128, ALPHA)
+        score = P.float().max(dim=1).values                                     # [kv, N]
+        sel_now = ca.position_ids[0][0].cpu()
+        for b in range(B):
+            n = int(ncnt[b])
+            assert 0 < n <= 64, (step, b, n)
+            ids = nids[b, :n].tolist()
+            assert len(set(ids)) == n and not (set(ids) & set(sel_now[b].tolist())), (step, b)
+            slot_of = {int(c): j for j, c in enumerate(lm_idx[b].tolist())}
+            sc = torch.tensor([float(score[b, slot_of[c]]) for c in ids])
+            srt = score[b].sort(descending=True).values
+            assert float(sc.max()) <= float(srt[S - 1]), (step, b)
+            near_quality.append(float((sc >= srt[min(S + 63, N - 1)]).float().mean()))
         _gate_up_with_near_pull(ca, 0, gw)
         _check_staging_invariant(ca, 0)
         staged_total += int((ca.near_published_ids(0) >= 0).sum())
     assert staged_total > 0 and served > 0, (staged_total, served)
+    assert sum(near_quality) / len(near_quality) > 0.8, sum(near_quality) / len(near_quality)
     try:
         from util import open_parity_record
         with open_parity_record("near_miss_staging.txt") as f:
