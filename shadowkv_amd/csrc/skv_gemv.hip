@@ -15,6 +15,10 @@
 #include "skv_early.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef SKV_GEMV_PRE_R2
+#define SKV_GEMV_PRE_R2 4      // k-steps of weights a two-row wave of the NORM variant requests before its norm prologue (round 5: all 8
+                               // up front - 142 VGPRs - measured 228.8-230.1 tokens/s against 230.3-231.3 with 4 on one box: not kept)
+#endif
 
 // NORM variant (K == 4096): x is the pre-norm hidden state; every BLOCK recomputes h = x + residual (bf16), the
 // RMS statistics and xn = bf16(h * rstd * w_norm) cooperatively (256 threads x 16 elements, through LDS), so
@@ -86,10 +90,11 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     }
     const bf16_t* xp = x + 8 * lane;
     // the first weight segments do not depend on the norm prologue: get them in flight before it
-    u32x4 wpre[NORM ? R : 1][4];
+    constexpr int PRE = (NORM && R <= 2) ? SKV_GEMV_PRE_R2 : 4;
+    u32x4 wpre[NORM ? R : 1][PRE];
     if (NORM) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PRE; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 wpre[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)u * 512));
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
                 if (!NORM) xv[u] = *reinterpret_cast<const u32x4*>(xp + (size_t)(ks + u) * 512);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (NORM && ks == 0) wv[r][u] = wpre[r][u];
+                    if (NORM && ks + u < PRE) wv[r][u] = wpre[r][ks + u];
                     else wv[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[r] + (size_t)(ks + u) * 512));
                 }
             }
