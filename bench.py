@@ -114,6 +114,7 @@ def build_model(workload, args, rank, dev, layout=None, overlap=None, resident_s
             and model.kv_cache.select_sets >= 128 and (args.batch == 1 or args.early_fetch_batches)):
         # (small budgets - config 0's 32 chunks per head - have too few misses for the link to matter: 273.8 tokens/s without the
         # early fetch, 268.8 with it)
+        model.kv_cache.near_lists = args.near_lists
         model.kv_cache.enable_early_fetch(early_max=None if args.early_fetch < 0 else args.early_fetch, margin=args.early_margin,
                                           near=args.batch == 1 and (args.near_fetch == 1 or (args.near_fetch < 0 and model.kv_cache.num_key_value_groups <= 4)))
     torch.cuda.synchronize()
@@ -921,6 +922,9 @@ def main(argv=None):
                          "for the NEXT step (near misses: a third of them are selected next; profiles/r05_near_fetch.txt: +2-3 %% on "
                          "the 8-KV-head shapes, nothing on the 4-KV-head ones); needs the early fetch and the fused selection; "
                          "identical results.  -1 (default): on for G <= 4 at one sequence per GPU")
+    ap.add_argument("--near-lists", type=int, default=1, choices=[1, 2],
+                    help="near-miss lists staged ahead: 1 (default) = ranks S+1 .. S+64 under the gate/up launch; 2 = also S+65 .. S+128 "
+                         "under the down projection (measured: a loss - the 20 us down GEMV cannot hide a round of host reads)")
     ap.add_argument("--early-fetch-batches", type=int, default=0, choices=[0, 1],
                     help="early fetch for --batch > 1 as well (one pull workgroup per head, 256 / (batch x KV heads) chunks each); "
                          "off by default: measured 595.3 vs 594.9 tokens/s at bs 8, 769.3 vs 761.0 at bs 24 - the selection is a small "

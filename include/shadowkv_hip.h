@@ -391,10 +391,10 @@ SKV_EXPORT int skv_select_chunks_fused(const void* q, const void* landmarks, con
  * [B][G][2], 2 flag counts i32 [B][T], 3 flagged slots i32 [B][T][16], 4 pulled count i32 [B], 5 pulled chunk ids i32
  * [B][early_max], 6 staging index per chunk i16 [B][n_chunks], 7 staging [B][early_max][2048 B] - EIGHT entries.
  * skv_early_state_offsets2 writes the first n_out (<= SKV_EARLY_STATE_REGIONS) entries: 8, 9 see skv_early_state_set_landmark_map;
- * 10 near-miss count i32 [B], 11 near-miss list i32 [B][64], 12 near misses staged now i32 [B][SKV_NEAR_SLOTS] (round 5:
+ * 10 near-miss counts i32 [2][B], 11 near-miss lists i32 [2][B][64], 12 near misses staged now i32 [2][B][64] (round 5: two lists;
  * region 7, the staging, holds early_max + SKV_NEAR_SLOTS slots per (batch, head); see skv_norm_gemv_near_pull_bf16). */
 #ifndef SKV_NEAR_SLOTS
-#define SKV_NEAR_SLOTS 64
+#define SKV_NEAR_SLOTS 128
 #endif
 #define SKV_EARLY_STATE_REGIONS 13
 SKV_EXPORT size_t skv_early_state_bytes(int blocks, int groups, int n_landmarks, int n_chunks, int early_max);
@@ -497,6 +497,12 @@ SKV_EXPORT int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const 
                                             void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
                                             int n_landmarks, int n_chunks, int early_max, const void* v_host,
                                             long long host_block_stride, int pull_parts, skv_stream_t stream);
+/* The same role for near-miss list `list` (0: the 64 candidates just below the selection, what the call above stages; 1: the next
+ * 64, staging slots early_max + 64 ..) in a plain one-token GEMV launch with N <= 8192 rows - skv_gemv_bf16, the layer's down
+ * projection (bias: the residual riding in the bias slot, or NULL).  Same GEMV result. */
+SKV_EXPORT int skv_gemv_near_pull_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, void* early_state,
+                                       int blocks, int groups, int n_landmarks, int n_chunks, int early_max, const void* v_host,
+                                       long long host_block_stride, int pull_parts, int list, skv_stream_t stream);
 /* The lm_head and the sampler without streaming the logit row through one CU (round 4): skv_norm_gemv_rangemax_bf16 is
  * skv_norm_gemv_bf16 (no fused SiLU) that ALSO leaves, per 16 consecutive outputs, the largest one as an order-preserving
  * 16-bit key (bf16 x >= 0: x | 0x8000; x < 0: ~x) in range_max[N / 16] (N % 16 == 0); skv_sample_topk_advance_ranges is

@@ -357,7 +357,7 @@ int skv_select_chunks_inplace_early(const void* q, const void* landmarks, const 
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    EarlyHooks eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
+    EarlyHooks eh = skv_early_hooks(es, blocks, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
                                     resident_sets, n_chunks, early_max);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;
@@ -411,7 +411,7 @@ int skv_select_chunks_fused(const void* q, const void* landmarks, const int64_t*
         if (!landmark_idx || !v_host || (host_block_stride % 8) || n_chunks < 1 || early_max < 1 || early_max > 128) return SKV_ERR_ARG;
         if (n_landmarks > 65536 || resident_sets > 1024 || n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;
         const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-        eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks, resident_sets,
+        eh = skv_early_hooks(es, blocks, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks, resident_sets,
                              n_chunks, early_max);
         hooks = &eh;
     }
@@ -436,7 +436,7 @@ int skv_select_chunks_early(const void* q, const void* landmarks, const int64_t*
     hipStream_t st = (hipStream_t)stream;
     SelectWs w = carve_select_ws(workspace, blocks, groups, n_landmarks);
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    EarlyHooks eh = skv_early_hooks(es, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
+    EarlyHooks eh = skv_early_hooks(es, blocks, groups, margin, landmark_idx, cached_pos_ids, v_host, host_block_stride, n_landmarks,
                                     select_sets, n_chunks, early_max);
     int rc = skv_launch_score(q, landmarks, w.D, w.pmax, w.psum, blocks, groups, n_landmarks, alpha, st, &eh);
     if (rc != SKV_OK) return rc;

@@ -106,7 +106,8 @@ __device__ __forceinline__ void skv_early_prep_role(const EarlyHooks& eh, int b,
     for (int k = 0; k < 4; ++k) my_res[k] = tid + k * THREADS < R ? eh.resident[(size_t)b * R + tid + k * THREADS] : -1ll;
     // chunks staged AHEAD of this step (near misses of the previous one, skv_near_pull_role) count as resident here: their
     // bytes are in staging already and early_of names them - flagging them again would pull them twice
-    const int my_near = (eh.near_pub != nullptr && tid < SKV_NEAR_SLOTS) ? eh.near_pub[(size_t)b * SKV_NEAR_SLOTS + tid] : -1;
+    const int my_near = (eh.near_pub != nullptr && tid < SKV_NEAR_SLOTS)
+                            ? eh.near_pub[((size_t)(tid >> 6) * eh.near_B + b) * SKV_NEAR_MAX + (tid & 63)] : -1;     // (both lists)
     for (int i = tid; i < words; i += THREADS) s_bits[i] = 0;
     // (only an entry that still names this slot: the chunk may have been staged AHEAD since - skv_near_pull_role publishes it under
     // a slot >= E - and that entry must survive; the load is one more request of this round trip, the store follows it)
@@ -271,7 +272,7 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
 // Nothing here can change a result: a staging slot is published (near_pub, early_of) only with the host table's bytes of
 // the chunk it names; a chunk's old entry is cleared before its slot is overwritten, both by this workgroup, in this order,
 // behind a barrier; everything is consumed by LATER launches.  An entry is only cleared if it still names this slot.
-// smem: 4 * 64 + 8 ints.
+// smem: 6 * 64 + 8 ints.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef SKV_NEAR_PULL_CAP
 #define SKV_NEAR_PULL_CAP 32       // chunks one workgroup of the pull role stages per launch = ONE round of requests (the rest of the list waits a step; measured: 64 / 32 / 16 -> 230.9 / 231.7 / 228.3 tokens/s, 226.8 without the role)
@@ -281,14 +282,16 @@ __device__ __forceinline__ void skv_early_prep_pull_role(const EarlyHooks& eh, i
 #endif
 __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, int tid, int* smem) {
     constexpr int NL = SKV_NEAR_MAX;
-    static_assert(NL == 64 && SKV_NEAR_SLOTS == 64, "one wave reconciles: the list and a part's slots in 64-bit ballots");
-    const int PARTS = np.parts, PS = SKV_NEAR_SLOTS / PARTS;               // (parts in {1, 2, 4}: checked by the launcher)
+    static_assert(NL == 64, "one wave reconciles: the list and a part's slots in 64-bit ballots");
+    const int PARTS = np.parts, PS = NL / PARTS;                           // (parts in {1, 2, 4}: checked by the launcher)
     const int b = blk / PARTS, part = blk % PARTS;
     int* const s_new = smem;              // [NL] this step's near misses of this part (-1: none / another part's)
     int* const s_old = smem + NL;         // [<= 64] staged now in this part's slots
     int* const s_slot = s_old + 64;       // [<= 64] local slot of the i-th chunk to pull
     int* const s_id = s_slot + 64;        // [<= 64] its id
-    int* const s_n = s_id + 64;           // [1] chunks to pull
+    int* const s_n = s_id + 64;           // [8] chunks to pull
+    int* const s_onew = s_n + 8;          // [NL] the other list's near misses of this step (kept if staged here)
+    int* const s_opub = s_onew + NL;      // [NL] what the other list's slots hold (not pulled again)
     const int n_chunks = np.n_chunks, E = np.E;
     const int slot0 = part * PS;          // first near slot of this part
     if (tid < NL) {
@@ -297,9 +300,12 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
         if (n < 0 || n >= n_chunks || n % PARTS != part) n = -1;
         s_new[tid] = n;
         if (tid < PS) {
-            const int o = np.near_pub[(size_t)b * SKV_NEAR_SLOTS + slot0 + tid];
+            const int o = np.near_pub[(size_t)b * NL + slot0 + tid];
             s_old[tid] = (o >= 0 && o < n_chunks) ? o : -1;
         }
+        const int ocnt = min(max(np.other_cnt[b], 0), NL);
+        s_onew[tid] = tid < ocnt ? np.other_ids[(size_t)b * NL + tid] : -1;
+        s_opub[tid] = np.other_pub[(size_t)b * NL + tid];
     }
     __syncthreads();
     if (tid < NL) {                       // wave 0
@@ -307,8 +313,9 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
         bool keep = false, fresh = n >= 0;
 #pragma unroll 8
         for (int i = 0; i < NL; ++i) {
-            keep |= o >= 0 && s_new[i] == o;
+            keep |= o >= 0 && (s_new[i] == o || s_onew[i] == o);    // (wanted by either list: stays where it is)
             if (i < tid) fresh &= s_new[i] != n;          // (the list holds distinct ids; a duplicate would be staged once)
+            fresh &= s_opub[i] != n;                       // (staged by the other list's launch already)
         }
         for (int j = 0; j < PS; ++j) fresh &= s_old[j] != n;
         const unsigned long long slots_m = PS >= 64 ? ~0ull : ((1ull << (PS & 63)) - 1ull);
@@ -325,7 +332,7 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
                 s_id[k] = n;
                 const int old = s_old[e];
                 // the slot's old chunk: unpublished before its bytes are overwritten (only if the entry still names this slot)
-                if (old >= 0 && np.early_of[(size_t)b * n_chunks + old] == (short)(E + slot0 + e))
+                if (old >= 0 && np.early_of[(size_t)b * n_chunks + old] == (short)(E + np.slot_base + slot0 + e))
                     np.early_of[(size_t)b * n_chunks + old] = (short)-1;
             }
         }
@@ -335,7 +342,7 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
     __syncthreads();
     const int n_pull = s_n[0];
     const u32x4* const hb = reinterpret_cast<const u32x4*>(np.v_host) + (long long)b * np.v_host_stride_u128;
-    u32x4* const sb = reinterpret_cast<u32x4*>(np.staging) + ((size_t)b * (E + SKV_NEAR_SLOTS) + E + slot0) * 128;
+    u32x4* const sb = reinterpret_cast<u32x4*>(np.staging) + ((size_t)b * (E + SKV_NEAR_SLOTS) + E + np.slot_base + slot0) * 128;
     // chunk = 128 units of 16 B; 256 threads: two chunks per pass, SKV_NEAR_INFLIGHT requests per thread in flight
     // (unconditional loads through a selected pointer, as in skv_early_pull_role)
     for (int r0 = 0; r0 * 256 < n_pull * 128; r0 += SKV_NEAR_INFLIGHT) {
@@ -353,7 +360,7 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
         }
     }
     if (tid < n_pull) {                   // publish (read by later launches only)
-        np.near_pub[(size_t)b * SKV_NEAR_SLOTS + slot0 + s_slot[tid]] = s_id[tid];
-        np.early_of[(size_t)b * n_chunks + s_id[tid]] = (short)(E + slot0 + s_slot[tid]);
+        np.near_pub[(size_t)b * NL + slot0 + s_slot[tid]] = s_id[tid];
+        np.early_of[(size_t)b * n_chunks + s_id[tid]] = (short)(E + np.slot_base + slot0 + s_slot[tid]);
     }
 }

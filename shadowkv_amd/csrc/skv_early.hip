@@ -12,9 +12,8 @@ __global__ void skv_early_init_kernel(float* dthr, int n_dthr, int* ints, int n_
     for (long long k = i; k < n_ids; k += stride) early_ids[k] = -1;  // every staging slot unused
     for (long long k = i; k < n_of; k += stride) early_of[k] = (short)-1;
     for (long long k = i; k < n_map; k += stride) map_ok[k] = 0;      // no slot -> id map yet: the list role gathers
-    for (long long k = i; k < n_map; k += stride) near_cnt[k] = 0;    // (n_map = B) no near-miss list, nothing staged ahead
-    for (long long k = i; k < (long long)n_map * SKV_NEAR_MAX; k += stride) near_ids[k] = -1;
-    for (long long k = i; k < (long long)n_map * SKV_NEAR_SLOTS; k += stride) near_pub[k] = -1;
+    for (long long k = i; k < (long long)SKV_NEAR_LISTS * n_map; k += stride) near_cnt[k] = 0;    // (n_map = B) no near-miss lists, nothing staged ahead
+    for (long long k = i; k < (long long)SKV_NEAR_LISTS * n_map * SKV_NEAR_MAX; k += stride) near_ids[k] = near_pub[k] = -1;
 }
 
 // slot -> chunk id map of one head (EarlyHooks::gap_slots): the landmark ids lm_idx[b][0 .. N) are chunk ids in ascending order

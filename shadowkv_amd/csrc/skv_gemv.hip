@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void skv_gemv_kernel(const bf16_t* __restrict_
     int bx = blockIdx.x;
     if constexpr (NEARP) {
         if (bx < np.blocks) {
-            __shared__ int s_near[4 * 64 + 8];
+            __shared__ int s_near[6 * 64 + 8];
             skv_near_pull_role(np, bx, threadIdx.x, s_near);
             return;
         }
@@ -299,13 +299,20 @@ static int launch_gemv(const void* W, const void* x, const void* bias, void* y, 
     if (qkv) qe = *qkv;
     if (K % 8 || K < 512) return SKV_ERR_UNSUPPORTED;
     if (norm && (K != 4096 || !w_norm)) return SKV_ERR_UNSUPPORTED;
-    if (near) {          // the gate/up launch of a layer with the near-miss pull role in front of its grid
-        if (!norm || !fuse_silu_mul || qkv || range_max || (N % 2) || bias || near->blocks < 1 || near->E + SKV_NEAR_SLOTS > 32767)
+    if (near) {          // a launch of a layer's dense tail with the near-miss pull role in front of its grid
+        if (qkv || range_max || near->blocks < 1 || near->E + SKV_NEAR_SLOTS > 32767) return SKV_ERR_UNSUPPORTED;
+        if (norm && fuse_silu_mul && !(N % 2) && !bias) {                    // gate/up: list 0
+            const int I = N / 2, grid = (I + 7) / 8;
+            hipLaunchKernelGGL((skv_gemv_kernel<4, true, true, false, false, true>), dim3(near->blocks + grid), dim3(256), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, I, (const bf16_t*)residual,
+                               (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe, (uint16_t*)nullptr, *near);
+        } else if (!norm && !fuse_silu_mul && N <= 8192) {                   // down projection (two rows per wave): list 1
+            hipLaunchKernelGGL((skv_gemv_kernel<2, false, false, false, false, true>), dim3(near->blocks + (N + 7) / 8), dim3(256), 0, st,
+                               (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, 0, (const bf16_t*)residual,
+                               (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe, (uint16_t*)nullptr, *near);
+        } else {
             return SKV_ERR_UNSUPPORTED;
-        const int I = N / 2, grid = (I + 7) / 8;
-        hipLaunchKernelGGL((skv_gemv_kernel<4, true, true, false, false, true>), dim3(near->blocks + grid), dim3(256), 0, st,
-                           (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)y, N, K, I, (const bf16_t*)residual,
-                           (const bf16_t*)w_norm, (bf16_t*)h_out, eps, qe, (uint16_t*)nullptr, *near);
+        }
         return hipGetLastError() == hipSuccess ? SKV_OK : SKV_ERR_LAUNCH;
     }
     if (range_max) {     // the lm_head with the sampler's range keys: norm prologue, whole workgroups of 16 rows
@@ -362,18 +369,37 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
     return launch_gemv(W, x, bias, y, N, K, fuse_silu_mul, residual, norm_weight, h_out, eps, true, (hipStream_t)stream);
 }
 
-extern "C" int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
-                                            void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
-                                            int n_landmarks, int n_chunks, int early_max, const void* v_host,
-                                            long long host_block_stride, int pull_parts, skv_stream_t stream) {
+static int near_pull_of(NearPull& np, void* early_state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,
+                        const void* v_host, long long host_block_stride, int pull_parts, int list) {
     if (pull_parts != 1 && pull_parts != 2 && pull_parts != 4) return SKV_ERR_ARG;
+    if (list < 0 || list >= SKV_NEAR_LISTS) return SKV_ERR_ARG;
     if (!early_state || !v_host || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1 || early_max > 128 ||
         (host_block_stride % 8))
         return SKV_ERR_ARG;
     if (n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;      // (the early state's limit, skv_select_chunks_fused)
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    const NearPull np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max, pull_parts);
+    np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max, pull_parts, list);
+    return SKV_OK;
+}
+
+extern "C" int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
+                                            void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
+                                            int n_landmarks, int n_chunks, int early_max, const void* v_host,
+                                            long long host_block_stride, int pull_parts, skv_stream_t stream) {
+    NearPull np{};
+    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, 0);
+    if (rc != SKV_OK) return rc;
     return launch_gemv(W, x, nullptr, y, N, K, 1, residual, norm_weight, h_out, eps, true, (hipStream_t)stream, nullptr, nullptr, &np);
+}
+
+// the down projection (skv_gemv_bf16, N <= 8192) with the pull role of near-miss list `list` (1: ranks S + 65 .. S + 128)
+extern "C" int skv_gemv_near_pull_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, void* early_state,
+                                       int blocks, int groups, int n_landmarks, int n_chunks, int early_max, const void* v_host,
+                                       long long host_block_stride, int pull_parts, int list, skv_stream_t stream) {
+    NearPull np{};
+    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, list);
+    if (rc != SKV_OK) return rc;
+    return launch_gemv(W, x, bias, y, N, K, 0, nullptr, nullptr, nullptr, 0.f, false, (hipStream_t)stream, nullptr, nullptr, &np);
 }
 
 extern "C" int skv_norm_gemv_rangemax_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,

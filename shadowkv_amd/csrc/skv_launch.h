@@ -84,10 +84,13 @@ struct EarlyHooks {
     // fell just short of this step's selection (near_ids / near_cnt, prediction only); the pull role of the gate/up GEMV
     // launch stages them (skv_near_pull_role) and publishes them in early_of with staging indices E .. E + SKV_NEAR_SLOTS - 1;
     // near_pub = the ids published there now (-1: slot unused) - the in-step list treats them like resident chunks.
-    int* near_cnt;              // [B]
-    int* near_ids;              // [B][SKV_NEAR_MAX]
-    const int* near_pub;        // [B][SKV_NEAR_SLOTS]
+    // SKV_NEAR_LISTS lists: list k holds the candidates ranked S + 64 k + 1 .. S + 64 (k + 1) and owns staging slots
+    // E + 64 k .. E + 64 k + 63; list 0 is staged by the gate/up launch, list 1 by the down-projection launch.
+    int* near_cnt;              // [LISTS][B]
+    int* near_ids;              // [LISTS][B][SKV_NEAR_MAX]
+    const int* near_pub;        // [LISTS][B][SKV_NEAR_MAX]
     int stage_stride;           // staging slots per (batch, head): E + SKV_NEAR_SLOTS
+    int near_B;                 // B (stride of the list index)
 };
 
 // Speculative early V fetch (round 3; skv_early.hip).  One state buffer per layer (skv_early_state_bytes), carved here.
@@ -110,7 +113,8 @@ struct EarlyHooks {
 // Measured on MI355X, tokens/s with / without the role on one box (profiles/r05_near_fetch.txt):
 //   8 KV heads (Llama-3.1-8B 122K): 1 part, 16 requests per thread in flight: 233.9 / 226.9 (+3.0 %); 4 parts: 227.3 / 226.7 (+0.3 %)
 // - the role costs the HBM-bound GEMV it rides in more the harder it pulls: a slow trickle from ~8 CUs is what hides.
-#define SKV_NEAR_SLOTS 64
+#define SKV_NEAR_LISTS 2
+#define SKV_NEAR_SLOTS (SKV_NEAR_LISTS * 64)
 struct EarlyState {
     float* dthr;
     float* finals;
@@ -143,14 +147,14 @@ static inline EarlyState skv_carve_early(void* base, int B, int G, int n_landmar
     e.staging = p + off;             off += skv_early_align((size_t)B * (E + SKV_NEAR_SLOTS) * 2048);
     e.gap_slots = (int*)(p + off);   off += skv_early_align((size_t)B * SKV_EARLY_GAPS * 4);
     e.map_ok = (int*)(p + off);      off += skv_early_align((size_t)B * 4);
-    e.near_cnt = (int*)(p + off);    off += skv_early_align((size_t)B * 4);
-    e.near_ids = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_MAX * 4);
-    e.near_pub = (int*)(p + off);    off += skv_early_align((size_t)B * SKV_NEAR_SLOTS * 4);
+    e.near_cnt = (int*)(p + off);    off += skv_early_align((size_t)SKV_NEAR_LISTS * B * 4);
+    e.near_ids = (int*)(p + off);    off += skv_early_align((size_t)SKV_NEAR_LISTS * B * SKV_NEAR_MAX * 4);
+    e.near_pub = (int*)(p + off);    off += skv_early_align((size_t)SKV_NEAR_LISTS * B * SKV_NEAR_MAX * 4);
     e.total = off;
     return e;
 }
 // the selection launches' view of a carved state (one place: every entry that takes an early state builds its hooks here)
-static inline EarlyHooks skv_early_hooks(const EarlyState& es, int groups, float margin, const int64_t* landmark_idx,
+static inline EarlyHooks skv_early_hooks(const EarlyState& es, int blocks, int groups, float margin, const int64_t* landmark_idx,
                                          const int64_t* resident, const void* v_host, long long host_block_stride,
                                          int n_landmarks, int resident_sets, int n_chunks, int E) {
     EarlyHooks eh{es.dthr, es.flag_cnt, es.flag_slot, es.finals, es.dthr, groups, margin, landmark_idx, resident,
@@ -162,23 +166,32 @@ static inline EarlyHooks skv_early_hooks(const EarlyState& es, int groups, float
     eh.near_ids = es.near_ids;
     eh.near_pub = es.near_pub;
     eh.stage_stride = E + SKV_NEAR_SLOTS;
+    eh.near_B = blocks;
     return eh;
 }
 
 // Near-miss staging ahead of the next step (round 5): the pull role that rides in the gate/up GEMV launch of a layer
 // (skv_gemv.hip: the first `blocks` workgroups of that launch; skv_near_pull_role in skv_early.h).
 struct NearPull {
-    const int* near_cnt;        // [B]   (top-k launch of this step)
+    const int* near_cnt;        // [B]   (top-k launch of this step; the launch's list)
     const int* near_ids;        // [B][SKV_NEAR_MAX]
-    int* near_pub;              // [B][SKV_NEAR_SLOTS] in / out: what staging slots E .. hold
+    int* near_pub;              // [B][SKV_NEAR_MAX] in / out: what the list's staging slots hold
     short* early_of;            // [B][n_chunks]
     void* staging;              // [B][E + SKV_NEAR_SLOTS][2 KiB]
     const void* v_host;
     long long v_host_stride_u128;
     int blocks;                 // B * parts pull workgroups (B = batch x KV heads)
     int n_chunks, E, parts;
+    int slot_base;              // first staging slot of the list behind E: 64 * list
+    // the OTHER list (staged by another launch of the same step): a chunk it holds is not pulled again, a chunk it wants is kept
+    const int* other_cnt;       // [B]
+    const int* other_ids;       // [B][SKV_NEAR_MAX]
+    const int* other_pub;       // [B][SKV_NEAR_MAX]
 };
 static inline NearPull skv_near_pull(const EarlyState& es, const void* v_host, long long host_block_stride, int B, int n_chunks, int E,
-                                     int parts) {
-    return NearPull{es.near_cnt, es.near_ids, es.near_pub, es.early_of, es.staging, v_host, host_block_stride / 8, B * parts, n_chunks, E, parts};
+                                     int parts, int list) {
+    return NearPull{es.near_cnt + (size_t)list * B, es.near_ids + (size_t)list * B * SKV_NEAR_MAX, es.near_pub + (size_t)list * B * SKV_NEAR_MAX,
+                    es.early_of, es.staging, v_host, host_block_stride / 8, B * parts, n_chunks, E, parts, 64 * list,
+                    es.near_cnt + (size_t)(1 - list) * B, es.near_ids + (size_t)(1 - list) * B * SKV_NEAR_MAX,
+                    es.near_pub + (size_t)(1 - list) * B * SKV_NEAR_MAX};
 }

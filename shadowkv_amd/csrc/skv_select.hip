@@ -1011,9 +1011,9 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
 #endif
         int thr, need_eq;
         // (with the early state: also the (S + SKV_NEAR_MAX)-th candidate score - the near misses below are the candidates between the two)
-        int thr_near = 0;
+        int thr_near[2] = {0, 0};
         t2_find_threshold<1>(w2, 2 * T2_THREADS - C, S, tid, s_hist, s_w, s_out, thr, need_eq, [] {},
-                             eh.near_ids != nullptr ? S + SKV_NEAR_MAX : 0, &thr_near);
+                             eh.near_ids != nullptr ? S + SKV_NEAR_MAX : 0, thr_near);
         TOPK_STAMP(17);
         if (thr >= 0x0100) {                                     // a normal bf16 number: the strictness argument holds
             if (eh.dthr_out != nullptr && tid < FG) {            // next step's flag thresholds (early fetch; prediction only)
@@ -1052,20 +1052,29 @@ __device__ __forceinline__ bool t3_fused_front(uint32_t (&w)[NW], const FusedTop
             if (eh.near_ids != nullptr) {
                 // Near misses (round 5; prediction only, nothing downstream of the selection reads it): the candidates that were
                 // evaluated exactly and fell short of the S-th score are the chunks most likely to enter the NEXT step's selection
-                // (tools/near_miss_sim.py: a third of the 64 nearest do).  The candidates from the S-th score down to the
-                // (S + SKV_NEAR_MAX)-th (thr_near; 0 = all of them when that score is outside the histogram window), the first
-                // SKV_NEAR_MAX in slot order, go to near_ids; the gate/up GEMV launch of this layer stages them while the link is
-                // idle (skv_near_pull_role).  One more block scan: the selection workgroup finishes microseconds before the
-                // launch's pull workgroups.
-                const int la = va && lo < thr && lo >= thr_near, lb = vb && hi < thr && hi >= thr_near;
-                const int nincl = block_scan_incl1(la + lb, searched ? s_w + 48 : s_w + 32, tid);   // (the row the last scan did not use)
-                int npos = nincl - (la + lb);
-                if (la) {
-                    if (npos < SKV_NEAR_MAX) eh.near_ids[(size_t)b * SKV_NEAR_MAX + npos] = (int)ida;
-                    ++npos;
+                // (tools/near_miss_sim.py: a third of the 64 nearest do, a quarter of the next 64).  The candidates from the S-th
+                // score down to the (S + 64)-th (thr_near[0]) go to list 0, those down to the (S + 128)-th to list 1 (0 = every
+                // candidate, when that score is outside the histogram window), the first SKV_NEAR_MAX in slot order each; the
+                // gate/up GEMV launch of this layer stages list 0 while the link is idle, the down-projection launch list 1
+                // (skv_near_pull_role).  One more block scan: the selection workgroup finishes microseconds before the launch's
+                // pull workgroups.
+                // list 0: scores in [thr_near[0], thr) - ranks S + 1 .. S + 64; list 1: [thr_near[1], thr_near[0]) - ranks S + 65 .. S + 128
+                const int la = va && lo < thr, lb = vb && hi < thr;
+                const int a0 = la && lo >= thr_near[0], b0 = lb && hi >= thr_near[0];
+                const int a1 = la && !a0 && lo >= thr_near[1], b1 = lb && !b0 && hi >= thr_near[1];
+                const int npk = (a0 + b0) | ((a1 + b1) << 16);
+                const int nincl = block_scan_incl1(npk, searched ? s_w + 48 : s_w + 32, tid);   // (the row the last scan did not use)
+                int p0 = (nincl & 0xffff) - (a0 + b0), p1 = (nincl >> 16) - (a1 + b1);
+                int* const l0 = eh.near_ids + (size_t)b * SKV_NEAR_MAX;
+                int* const l1 = eh.near_ids + ((size_t)eh.near_B + b) * SKV_NEAR_MAX;
+                if (a0) { if (p0 < SKV_NEAR_MAX) l0[p0] = (int)ida; ++p0; }
+                if (b0 && p0 < SKV_NEAR_MAX) l0[p0] = (int)idb;
+                if (a1) { if (p1 < SKV_NEAR_MAX) l1[p1] = (int)ida; ++p1; }
+                if (b1 && p1 < SKV_NEAR_MAX) l1[p1] = (int)idb;
+                if (tid == T2_THREADS - 1) {
+                    eh.near_cnt[b] = min(nincl & 0xffff, SKV_NEAR_MAX);
+                    eh.near_cnt[eh.near_B + b] = min(nincl >> 16, SKV_NEAR_MAX);
                 }
-                if (lb && npos < SKV_NEAR_MAX) eh.near_ids[(size_t)b * SKV_NEAR_MAX + npos] = (int)idb;
-                if (tid == T2_THREADS - 1) eh.near_cnt[b] = min(nincl, SKV_NEAR_MAX);
             }
             return true;
         }

@@ -154,14 +154,15 @@ __device__ __forceinline__ unsigned hash_slot(int id, int H) {
 // word; padding already rewritten to key 0, n_pad of them).  thr = the S-th largest key, need_eq = how many keys equal to
 // thr belong to the top S.  round0_extra() runs between the first histogram pass and its barrier (LDS work that overlaps).
 // s_hist [T2_BINS][T2_COPIES] zeroed by the caller before its first barrier; s_w [80], s_out [16] scratch.
-// need2 > S (optional, prediction only - the near-miss list of skv_select.hip): *thr2 = the need2-th largest key when it lies in
-// the first histogram window (else, or with fewer than need2 keys, 0 = "every key"); costs one more compare per thread.
+// need2 > S (optional, prediction only - the near-miss lists of skv_select.hip): thr2[0] = the need2-th largest key, thr2[1] = the
+// (2 need2 - S)-th, when they lie in the first histogram window (else, or with fewer keys, 0 = "every key"); costs two more
+// compares per thread.
 template <int NW, typename F>
 __device__ __forceinline__ void t2_find_threshold(const uint32_t (&w)[NW], const int n_pad, const int S, const int tid,
                                                   int* s_hist, int* s_w, int* s_out, int& thr, int& need_eq,
                                                   F round0_extra, const int need2 = 0, int* thr2 = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
-    if (need2 > 0 && tid == 0) s_out[2] = T2_BINS - 1;     // (visible behind barrier (A); rewritten between (C) and (D))
+    if (need2 > 0 && tid == 0) s_out[2] = s_out[3] = T2_BINS - 1;     // (visible behind barrier (A); rewritten between (C) and (D))
     {
         uint32_t m2 = w[0];
 #pragma unroll
@@ -220,12 +221,16 @@ __device__ __forceinline__ void t2_find_threshold(const uint32_t (&w)[NW], const
             const int tot = (c[0] + c[1]) + (c[2] + c[3]);
             const int incl = block_scan_incl1(tot, s_w + 16 * (round & 1), tid);      // barrier (C)
             int run = incl - tot;
-            if (need2 > 0 && round == 0 && run < need2 && incl >= need2) {
-                int r2 = run;
+            if (need2 > 0 && round == 0) {
+                const int need3 = 2 * need2 - need;              // (need == S in round 0)
+                if (run < need3 && incl >= need2) {
+                    int r2 = run;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    if (r2 < need2 && r2 + c[x] >= need2) s_out[2] = 4 * tid + x;
-                    r2 += c[x];
+                    for (int x = 0; x < 4; ++x) {
+                        if (r2 < need2 && r2 + c[x] >= need2) s_out[2] = 4 * tid + x;
+                        if (r2 < need3 && r2 + c[x] >= need3) s_out[3] = 4 * tid + x;
+                        r2 += c[x];
+                    }
                 }
             }
             if (run < need && incl >= need) {
@@ -241,7 +246,10 @@ __device__ __forceinline__ void t2_find_threshold(const uint32_t (&w)[NW], const
             __syncthreads();                               // (D)
             TOPK_STAMP(3);
             const int rel_thr = s_out[0], above = s_out[1];
-            if (need2 > 0 && round == 0) *thr2 = s_out[2] < T2_BINS - 1 ? base - s_out[2] : 0;
+            if (need2 > 0 && round == 0) {
+                thr2[0] = s_out[2] < T2_BINS - 1 ? base - s_out[2] : 0;
+                thr2[1] = s_out[3] < T2_BINS - 1 ? base - s_out[3] : 0;
+            }
             if (rel_thr < T2_BINS - 1) {
                 thr = base - rel_thr;
                 need_eq = need - above;

@@ -271,6 +271,9 @@ class ShadowKVCache_CPU:
         # tensor_op.norm_linear_decode(near_pull=)); the next step's fetch launch reads them from HBM.  Identical results.
         self.near_fetch = False
         self.near_pull_parts = None      # pull workgroups per (batch, head): None = about 8 in all (1 for 8 KV heads, 2 for 4)
+        self.near_lists = 1              # 1: only the gate/up launch stages (ranks S+1 .. S+64); 2: the down projection stages S+65 .. S+128
+        #                                  too - measured 217.3 tokens/s against 230.8 with one list (226.8 with none): the 20 us down GEMV is
+        #                                  too short to hide a round of host reads (profiles/r05_near_fetch.txt)
         self._copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
 
     # ------------------------------------------------------------------ bookkeeping
@@ -877,25 +880,31 @@ class ShadowKVCache_CPU:
         off = int(lib().skv_select_state_stats_offset(self.block_num, G))
         return self._sel_state[layer_idx][off:off + 8 * self.block_num].view(torch.int32).view(self.block_num, 2).cpu()
 
-    def near_pull_args(self, layer_idx):
-        """Arguments of tensor_op.norm_linear_decode(..., near_pull=) for this layer's gate/up launch, or None when the
-        near-miss staging is off (`near_fetch`, enable_early_fetch(near=True)): (early state, blocks, groups, landmarks,
-        chunks, early_max, V table, its per-head stride, pull workgroups per head)."""
+    def near_pull_args(self, layer_idx, which=0):
+        """Arguments of tensor_op.norm_linear_decode(..., near_pull=) for this layer's gate/up launch (which = 0: the list of
+        the 64 candidates just below the selection) or of tensor_op.linear_decode(..., near_pull=) for its down projection
+        (which = 1: the next 64; `near_lists` >= 2), or None when the near-miss staging is off (`near_fetch`,
+        enable_early_fetch(near=True)): (early state, blocks, groups, landmarks, chunks, early_max, V table, its per-head
+        stride, pull workgroups per head[, list])."""
+        if which >= self.near_lists:
+            return None
         ea = self._early
         if ea is None or not self.near_fetch or not self.fused_select or self._sel_state is None:
             return None
         if getattr(self, "_near_listed", -1) != layer_idx:       # this step's selection of the layer ran without the early state
             return None
         vhost = self.v_cache_cpu[layer_idx]
-        return (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],
+        args = (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],
                 ptr(vhost), vhost.stride(1), self.near_pull_parts or max(1, min(4, 8 // ea["blocks"])))
+        return args if which == 0 else args + (which,)
 
     def near_published_ids(self, layer_idx):
-        """int32 [blocks, 64]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 63
-        (SKV_NEAR_SLOTS); -1 = empty."""
+        """int32 [blocks, 128]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 127
+        (SKV_NEAR_SLOTS: list 0 in the first 64, list 1 in the second 64); -1 = empty."""
         e = self._early
         o, B = e["offsets"], self.block_num
-        return e["states"][layer_idx][o[12]:o[12] + 4 * B * 64].view(torch.int32).view(B, 64).cpu()
+        lists = e["states"][layer_idx][o[12]:o[12] + 4 * 2 * B * 64].view(torch.int32).view(2, B, 64).cpu()
+        return torch.cat((lists[0], lists[1]), dim=1)
 
     def _early_published_ids(self, layer_idx):
         """int32 [blocks, E]: the chunk id every staging slot was PUBLISHED with in the last step of this layer, -1 = unused.

@@ -263,7 +263,8 @@ class DecoderLM:
                                                          near_pull=near)
             if residual.shape[0] == 1:      # one sequence: the residual rides in the GEMV's bias slot (bf16(W.act) + residual,
                 #                             rounded like the separate add: same bits, one launch less)
-                return tensor_op.linear_decode(act, layer.down_proj, bias=residual, out=cur["out"])
+                near1 = None if near is None else self.kv_cache.near_pull_args(layer.layer_idx, 1)
+                return tensor_op.linear_decode(act, layer.down_proj, bias=residual, out=cur["out"], near_pull=near1)
             return torch.add(residual, tensor_op.linear_decode(act, layer.down_proj, out=cur["down"]), out=cur["out"])
         hs = residual + F.linear(attn_output, layer.wo)
         residual = hs
@@ -350,7 +351,7 @@ class DecoderLM:
                                                          layer.post_attention_layernorm_variance_epsilon,
                                                          layer.gate_up_proj, fuse_silu_mul=True,
                                                          near_pull=None if full or bs != 1 else c.near_pull_args(l))
-            x = tensor_op.linear_decode(act, layer.down_proj)
+            x = tensor_op.linear_decode(act, layer.down_proj, near_pull=None if full or bs != 1 else c.near_pull_args(l, 1))
         V = self.lm_head.shape[0]
         rm = None
         if self.sampler_ranges and not as_float and x.is_cuda and tensor_op.range_max_supported(x.numel(), x.shape[-1], V):

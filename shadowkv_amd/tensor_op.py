@@ -38,12 +38,22 @@ def silu_and_mul(out, x):
 MAX_GEMV_ROWS = 32   # token rows served by the native kernels (1: GEMV, 2..32: small-M MFMA kernel); more -> F.linear
 
 
-def linear_decode(x, w, bias=None, fuse_silu_mul=False, out=None):
+def linear_decode(x, w, bias=None, fuse_silu_mul=False, out=None, near_pull=None):
     """F.linear for decode-time activations (x [..., K] with a handful of token rows): one token -> the native GEMV,
     2..MAX_GEMV_ROWS tokens -> the native small-M MFMA kernel (weights stream once); falls back to F.linear for more
-    rows or shapes the kernels are not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x)."""
+    rows or shapes the kernels are not built for.  fuse_silu_mul: w = [gate; up] -> silu(gate.x) * (up.x).
+    near_pull (the down projection of a ShadowKV layer, one token, N <= 8192; ShadowKVCache_CPU.near_pull_args(layer, 1)): the
+    launch's first workgroups stage the second near-miss list of this step's selection (skv_gemv_near_pull_bf16); same y."""
     K = x.shape[-1]
     rows = x.numel() // K
+    if near_pull is not None:
+        N = w.shape[0]
+        if rows != 1 or fuse_silu_mul or N > 8192 or K % 32 or K < 512 or not x.is_contiguous() or not w.is_contiguous():
+            raise ValueError("near_pull rides in a one-token GEMV launch with at most 8,192 output rows")
+        y = out if out is not None else torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        check(lib().skv_gemv_near_pull_bf16(ptr(w), ptr(x), ptr(bias), ptr(y), N, K, *near_pull, current_stream_handle()),
+              "gemv_near_pull")
+        return y
     if rows > MAX_GEMV_ROWS or K % 32 or K < 512 or not x.is_contiguous() or not w.is_contiguous():
         out = F.linear(x, w, bias)
         return silu_and_mul_fused(out) if fuse_silu_mul else out

@@ -516,19 +516,20 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
         big.get_retrieval_position_ids(0, q)
 
 
-NEAR = 64     # SKV_NEAR_SLOTS: near-miss staging slots per (batch, head) behind the E in-step slots
+NEAR = 128    # SKV_NEAR_SLOTS: near-miss staging slots per (batch, head) behind the E in-step slots (two lists of 64)
 
 
 def _check_staging_invariant(cache, layer):
     """What the fetch launch relies on when it reads a chunk from staging instead of the host: early_of[chunk] = e implies that
     staging slot e holds that chunk's bytes and is published under its id - early_ids[e] for the in-step slots e < E (whichever
     workgroup published it: each pull workgroup of the fused selection publishes only the slots it fills, skv_early.h),
-    near_pub[e - E] for the slots E .. E + 63 staged ahead by the gate/up launch (round 5, skv_near_pull_role)."""
+    near_pub[e - E] for the slots E .. E + 127 staged ahead by the gate/up (list 0) and down-projection (list 1) launches (round 5,
+    skv_near_pull_role)."""
     ea = cache._early
     o, st = ea["offsets"], ea["states"][layer]
     B, E, nch = cache.block_num, ea["E"], ea["n_chunks"]
     ids = st[o[5]:o[5] + 4 * B * E].view(torch.int32).view(B, E).cpu()
-    near = st[o[12]:o[12] + 4 * B * NEAR].view(torch.int32).view(B, NEAR).cpu()
+    near = cache.near_published_ids(layer)                       # [B, 128]: list 0 | list 1
     of = st[o[6]:o[6] + 2 * B * nch].view(torch.int16).view(B, nch).cpu()
     staging = st[o[7]:o[7] + B * (E + NEAR) * 2048].view(torch.int16).view(B, E + NEAR, 1024).cpu()
     vh = cache.v_cache_cpu[layer].view(B, nch, 1024)
@@ -566,6 +567,15 @@ def _gate_up_with_near_pull(cache, layer, g):
     h1, y1 = tensor_op.norm_linear_decode(x, res, nw, 1e-5, w, fuse_silu_mul=True, near_pull=args)
     torch.cuda.synchronize()
     assert torch.equal(h0.view(torch.int16), h1.view(torch.int16)) and torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    # the down projection's launch (two rows per wave, the residual in the bias slot) with the pull role of list 1
+    a = torch.randn(1, 1, 1024, device=DEV, generator=g).bfloat16()
+    wd = (torch.randn(4096, 1024, device=DEV, generator=g) * 0.02).bfloat16()
+    d0 = tensor_op.linear_decode(a, wd, bias=h0)
+    args1 = cache.near_pull_args(layer, 1)
+    assert args1 is not None and args1[-1] == 1
+    d1 = tensor_op.linear_decode(a, wd, bias=h0, near_pull=args1)
+    torch.cuda.synchronize()
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
 
 
 @pytest.mark.parametrize("kv_heads,glm,budget", [(8, False, 2048), (4, True, 2048), (8, False, 1024)])
@@ -577,6 +587,7 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
     L = 16384
     ca, cs, g = _headline_cache(kv_heads, glm, L=L, seed=41, budget=budget)
     cb, _, _ = _headline_cache(kv_heads, glm, L=L, seed=41, budget=budget)
+    ca.near_lists = 2            # (both lists: the second one, staged by the down projection's launch, is off by default - it does not pay)
     ca.enable_early_fetch(near=True)
     cb.enable_early_fetch()
     assert ca.near_pull_args(0) is None and cb.near_pull_args(0) is None      # (no selection has left a near-miss list yet)
@@ -585,7 +596,7 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
     gw = torch.Generator(device=DEV).manual_seed(3)
     B, S = ca.block_num, ca.select_sets
     served = staged_total = 0
-    near_quality = []
+    near_quality = [[], []]
     for step in range(8):
         q = (q.float() + 0.3 * torch.randn(1, 32, 1, 128, device=DEV, generator=g)).bfloat16()
         before = [set(r[r >= 0].tolist()) for r in ca.near_published_ids(0)]        # staged ahead, as this step's fetch sees it
@@ -609,8 +620,8 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
         # the near-miss list this step's top-k launch left: distinct landmark chunks that were NOT selected, none scoring above
         # the S-th score, and (prediction quality, not a contract) mostly the ranks S + 1 .. S + 64 of the oracle's exact scores
         o, st = ca._early["offsets"], ca._early["states"][0]
-        ncnt = st[o[10]:o[10] + 4 * B].view(torch.int32).cpu()
-        nids = st[o[11]:o[11] + 4 * B * 64].view(torch.int32).view(B, 64).cpu()
+        ncnt = st[o[10]:o[10] + 4 * 2 * B].view(torch.int32).view(2, B).cpu()
+        nids = st[o[11]:o[11] + 4 * 2 * B * 64].view(torch.int32).view(2, B, 64).cpu()
         lm, lm_idx = ca.k_landmark[0][0].cpu().contiguous(), ca.k_landmark_idx[0][0].cpu()
         N, Gq = lm.shape[1], 32 // kv_heads
         Dm = torch.zeros(kv_heads, Gq, N, dtype=torch.bfloat16); P = torch.zeros_like(Dm)
@@ -620,20 +631,27 @@ def test_near_miss_staging_changes_no_bit(kv_heads, glm, budget):
         score = P.float().max(dim=1).values                                     # [kv, N]
         sel_now = ca.position_ids[0][0].cpu()
         for b in range(B):
-            n = int(ncnt[b])
-            assert 0 < n <= 64, (step, b, n)
-            ids = nids[b, :n].tolist()
-            assert len(set(ids)) == n and not (set(ids) & set(sel_now[b].tolist())), (step, b)
             slot_of = {int(c): j for j, c in enumerate(lm_idx[b].tolist())}
-            sc = torch.tensor([float(score[b, slot_of[c]]) for c in ids])
             srt = score[b].sort(descending=True).values
-            assert float(sc.max()) <= float(srt[S - 1]), (step, b)
-            near_quality.append(float((sc >= srt[min(S + 63, N - 1)]).float().mean()))
+            both = []
+            for k in range(2):
+                n = int(ncnt[k, b])
+                assert 0 <= n <= 64 and (k == 1 or n > 0), (step, b, k, n)
+                ids = nids[k, b, :n].tolist()
+                both += ids
+                if not ids:
+                    continue
+                sc = torch.tensor([float(score[b, slot_of[c]]) for c in ids])
+                assert float(sc.max()) <= float(srt[S - 1]), (step, b, k)
+                lo = srt[min(S + 64 * (k + 1) - 1, N - 1)]
+                near_quality[k].append(float((sc >= lo).float().mean()))
+            assert len(set(both)) == len(both) and not (set(both) & set(sel_now[b].tolist())), (step, b)
         _gate_up_with_near_pull(ca, 0, gw)
         _check_staging_invariant(ca, 0)
         staged_total += int((ca.near_published_ids(0) >= 0).sum())
     assert staged_total > 0 and served > 0, (staged_total, served)
-    assert sum(near_quality) / len(near_quality) > 0.8, sum(near_quality) / len(near_quality)
+    for k in range(2):          # list k: mostly the ranks up to S + 64 (k + 1) of the oracle's exact scores
+        assert near_quality[k] and sum(near_quality[k]) / len(near_quality[k]) > 0.8, (k, near_quality[k][:8])
     try:
         from util import open_parity_record
         with open_parity_record("near_miss_staging.txt") as f:
@@ -647,6 +665,7 @@ def test_near_miss_staging_survives_clear_and_a_new_prompt():
     """clear() retires the per-prompt early state with its near-miss slots; H2D() after the next prefill re-creates it (empty):
     nothing staged for the old prompt can be read for the new one."""
     ca, cs, g = _headline_cache(8, False, L=16384, seed=43)
+    ca.near_lists = 2
     ca.enable_early_fetch(near=True)
     kv_len = ca.sparse_end + 2
     gw = torch.Generator(device=DEV).manual_seed(5)
