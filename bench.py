@@ -1183,6 +1183,7 @@ def main(argv=None):
                 sec.append(dict(name=wl, workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
                                 path="in-place layout, attention inside the fetch launch" if model.kv_cache.can_overlap_attention() else "plain fetch launch + standalone attention",
                                 early_fetch_chunks_per_head=None if model.kv_cache._early is None else model.kv_cache._early["E"],
+                                near_fetch=bool(model.kv_cache._early is not None and model.kv_cache.near_fetch),
                                 value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1),
                                 scan_roofline={"us_per_launch": round(rf["us_per_launch"], 3), "algorithmic_bytes_per_launch": rf["algorithmic_bytes"],
