@@ -24,6 +24,17 @@ What is captured per case (bf16 stored as uint16):
   offload class `ShadowKVCache_CPU`  (models/kv_cache.py:509-980), prefill half only
     cpu_*                    same state as above + initial position_ids and the
                              initial fill of the sparse region     (:921-970)
+  offload class, DECODE half (round 5; trace_<case>.json, TRACE_CASES of gen_inputs.py)
+    the reference's unmodified ShadowKVCache_CPU (models/kv_cache.py:983-1176, 1227-1271) and models/tensor_op.py:171-238
+    over tests/golden/trace_standin.py registered as `kernels.shadowkv` (records every argument, carries the call out
+    through oracle/): 2 layers x 4 steps in LLM.layer_compute's order - every call across the native boundary and the
+    state after every (step, layer); trace_<case>_factors.npz: the reference's U / SV for two cases (LAPACK's bits
+    differ between CPUs); run_trace / load_reference_offload below
+  offload class, sub-batched prefill (subbatch_prefill.json): LLM.batch_prefill's pattern (models/base.py:533-543)
+
+  python tests/golden/make_golden.py                 everything (~25 s)
+  python tests/golden/make_golden.py --only-traces   the round-5 JSON fixtures only
+Regeneration is deterministic: the JSON files come out byte-identical, the .npz arrays array-identical.
 """
 import importlib.util
 import os
