@@ -1093,7 +1093,7 @@ def main(argv=None):
                     cache.near_fetch = False
                     rn = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
                     cache.near_fetch = True
-                    near_rec = dict(slots_per_head=64, pull_workgroups_per_head=cache.near_pull_args(0)[-1],
+                    near_rec = dict(slots_per_head=64, pull_workgroups_per_head=cache.near_pull_parts or max(1, min(4, 8 // cache.block_num)),
                                     value_without=dict(value=round(rn["value"], 2), ms_per_step=round(rn["ms_per_step"], 4), steps=short["steps"]),
                                     note="near-miss staging ahead of the next step (round 5, csrc/skv_early.h skv_near_pull_role): the gate/up "
                                          "GEMV launch of every layer stages the chunks that fell just short of the step's selection; "
