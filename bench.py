@@ -997,298 +997,313 @@ def main(argv=None):
     per_rank = gather_rank_records(my_rec, world)
 
     if rank == 0:
-        extras = {}
-        detail = world == 1 and not args.no_extras and not full
-        roof = measure_score_kernel(model) if not full else None
-        if detail:
-            path_ms, path_hit = measure_path_only(model, args.walk_step)
-            wbytes = model.weight_bytes()
-            B, N = cache.block_num, cache.k_landmark.shape[-2]
-            miss = 1.0 - path_hit
-            path_bytes = model.num_layers * (B * N * 256 + B * cache.select_sets * 8
-                                              + miss * B * budget * (cache.rank * 2 + 2 * 256) + B * 128 * cache.rank * 2
-                                              + 2 * B * cache.sparse_end * 256)
-            pcie_gbs = miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9
-            extras = dict(path_ms_per_step=round(path_ms, 3), path_chunk_hit_rate=round(path_hit, 4),
-                          weight_bytes=wbytes, path_algorithmic_bytes=int(path_bytes),
-                          step_hbm_frac_of_peak=round((wbytes + path_bytes) / (head["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
-                          path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
-                          pcie_gbs_in_path=round(pcie_gbs, 2), pcie_frac_of_spec=round(pcie_gbs / PCIE_PEAK_GBS, 3))
-            short = dict(steps=24, warmup=4)
-            ref_set = cache.resident_sets == cache.select_sets
-            if args.pin_hit_rate is None and args.mode == "graph" and args.query_mode == "walk" and ref_set:
-                sweep = []
-                for pin in (0.0, 0.6):            # the pinned extremes next to the walk's measured rate
-                    r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=7, pin_hit=pin)
-                    sweep.append(dict(pinned_hit_rate=pin, measured_hit_rate=round(r["hit_rate"], 4),
-                                      value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]))
-                extras["hit_rate_sweep"] = sweep
-            if args.layout == "inplace" and ref_set:   # the reference's slot order (hits compacted to the front), no overlap
-                # (same state: "slot i holds chunk position_ids[i]" is the invariant of both layouts)
-                model.chunk_layout, model.overlap_attention = "reference", False
-                r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
-                extras["value_reference_layout"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                                        chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
-                                                        note="--layout reference --overlap-attention 0: the reference's slot order bit for bit")
-                model.chunk_layout, model.overlap_attention = "inplace", bool(args.overlap_attention)
-            if ref_set and bs == 1:
-                extras["value_call_order"] = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step,
-                                                            seed=99 + rank)
-                strict = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False)
-                extras["value_call_order"]["without_lazy_value_fetch"] = dict(value=strict["value"], ms_per_step=strict["ms_per_step"])
-                inpl = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, inplace=True)
-                extras["value_call_order"]["with_inplace_methods"] = dict(
-                    value=inpl["value"], ms_per_step=inpl["ms_per_step"],
-                    note="kv_cache.inplace_methods: the same calls on the in-place layout (no staging launch for moved hits; same "
-                         "chunk sets, slot order differs from the reference's)")
-                refc = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False,
-                                      reference_calls=True)
-                extras["value_call_order"]["reference_launch_sequence"] = dict(
-                    value=refc["value"], ms_per_step=refc["ms_per_step"],
-                    note="kv_cache.reference_calls: the reference's OWN launch sequence across the native boundary (kv_cache.py:983-1176: "
-                         "batch_gemm_softmax -> torch.max / topk / gather -> reorder_keys_and_compute_offsets -> gather_copy_with_offsets -> "
-                         "gather_copy_d2d_with_offsets -> batch_gather_gemm -> apply_rotary_pos_emb_push_cache_opt) through the twelve "
-                         "kernels.shadowkv names - what swapping only the native module under the reference's Python gives; pinned call "
-                         "by call to a recording of the reference (tests/test_decode_trace.py)")
-                if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
-                    r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
-                                   seed=99 + rank)
-                    extras["value_eager"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
-                                                 note="--mode eager: the fused 9-launch step issued from Python every step (no hipGraph)")
-                    extras["value_call_order"]["fraction_of_eager_fused"] = round(extras["value_call_order"]["value"] / r["value"], 3)
-            if ref_set and args.layout == "inplace" and args.query_mode == "walk":
-                extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
-            try:     # which branch of the fused selection the heads took in the last step, over all layers
-                fs = [cache.fused_select_stats(l) for l in range(model.num_layers)]
-                if fs[0] is not None:
-                    st = torch.cat(fs)
-                    nh = st.shape[0]
-                    extras["fused_select"] = dict(
-                        heads=nh, level_held=int((st[:, 0] == 0).sum()), level_searched=int(((st[:, 0] & 1) != 0).sum()),
-                        every_slot_evaluated=int(((st[:, 0] & 2) != 0).sum()), mean_candidates=round(float(st[:, 1].float().mean()), 1),
-                        max_candidates=int(st[:, 1].max()), select_sets=cache.select_sets,
-                        note="(layer, KV head) pairs of the last decode step run on this state (same query walk as the timed run); results are identical on every branch")
-            except Exception as e:
-                print(f"[bench] fused-selection statistics failed: {e}", file=sys.stderr)
-            if cache._early is not None and args.mode == "graph":
-                # the speculative early V fetch: what it pulled / what the fetch launch then read from staging (last layer of
-                # one more eager step), and the same captured run without it
-                from shadowkv_amd import llama
-                ea = cache._early
-                stats = None
-                try:
-                    rewind(model, ctx)
-                    walk2 = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
-                    tok2 = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
-                    for _ in range(4):
-                        walk2.advance()
-                        tok2 = model.decode_step(tok2, temperature=0.6, q_table=walk2.qb)
-                    torch.cuda.synchronize()
-                    stats = cache.early_fetch_stats(model.num_layers - 1)
+        # The line must come out whatever happens in a secondary leg: everything behind the timed headline runs guarded; a failure
+        # is reported in the line (`bench_error`) and on stderr, with whatever was assembled until then.
+        out = None
+        try:
+            extras = {}
+            detail = world == 1 and not args.no_extras and not full
+            roof = measure_score_kernel(model) if not full else None
+            if detail:
+                path_ms, path_hit = measure_path_only(model, args.walk_step)
+                wbytes = model.weight_bytes()
+                B, N = cache.block_num, cache.k_landmark.shape[-2]
+                miss = 1.0 - path_hit
+                path_bytes = model.num_layers * (B * N * 256 + B * cache.select_sets * 8
+                                                  + miss * B * budget * (cache.rank * 2 + 2 * 256) + B * 128 * cache.rank * 2
+                                                  + 2 * B * cache.sparse_end * 256)
+                pcie_gbs = miss * model.num_layers * B * budget * 256 / (path_ms * 1e-3) / 1e9
+                extras = dict(path_ms_per_step=round(path_ms, 3), path_chunk_hit_rate=round(path_hit, 4),
+                              weight_bytes=wbytes, path_algorithmic_bytes=int(path_bytes),
+                              step_hbm_frac_of_peak=round((wbytes + path_bytes) / (head["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                              path_hbm_frac_of_peak=round(path_bytes / (path_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                              pcie_gbs_in_path=round(pcie_gbs, 2), pcie_frac_of_spec=round(pcie_gbs / PCIE_PEAK_GBS, 3))
+                short = dict(steps=24, warmup=4)
+                ref_set = cache.resident_sets == cache.select_sets
+                if args.pin_hit_rate is None and args.mode == "graph" and args.query_mode == "walk" and ref_set:
+                    sweep = []
+                    for pin in (0.0, 0.6):            # the pinned extremes next to the walk's measured rate
+                        r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=7, pin_hit=pin)
+                        sweep.append(dict(pinned_hit_rate=pin, measured_hit_rate=round(r["hit_rate"], 4),
+                                          value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]))
+                    extras["hit_rate_sweep"] = sweep
+                if args.layout == "inplace" and ref_set:   # the reference's slot order (hits compacted to the front), no overlap
+                    # (same state: "slot i holds chunk position_ids[i]" is the invariant of both layouts)
+                    model.chunk_layout, model.overlap_attention = "reference", False
+                    r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                    extras["value_reference_layout"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                            chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
+                                                            note="--layout reference --overlap-attention 0: the reference's slot order bit for bit")
+                    model.chunk_layout, model.overlap_attention = "inplace", bool(args.overlap_attention)
+                if ref_set and bs == 1:
+                    extras["value_call_order"] = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step,
+                                                                seed=99 + rank)
+                    strict = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False)
+                    extras["value_call_order"]["without_lazy_value_fetch"] = dict(value=strict["value"], ms_per_step=strict["ms_per_step"])
+                    inpl = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, inplace=True)
+                    extras["value_call_order"]["with_inplace_methods"] = dict(
+                        value=inpl["value"], ms_per_step=inpl["ms_per_step"],
+                        note="kv_cache.inplace_methods: the same calls on the in-place layout (no staging launch for moved hits; same "
+                             "chunk sets, slot order differs from the reference's)")
+                    refc = run_call_order(model, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank, lazy_v=False,
+                                          reference_calls=True)
+                    extras["value_call_order"]["reference_launch_sequence"] = dict(
+                        value=refc["value"], ms_per_step=refc["ms_per_step"],
+                        note="kv_cache.reference_calls: the reference's OWN launch sequence across the native boundary (kv_cache.py:983-1176: "
+                             "batch_gemm_softmax -> torch.max / topk / gather -> reorder_keys_and_compute_offsets -> gather_copy_with_offsets -> "
+                             "gather_copy_d2d_with_offsets -> batch_gather_gemm -> apply_rotary_pos_emb_push_cache_opt) through the twelve "
+                             "kernels.shadowkv names - what swapping only the native module under the reference's Python gives; pinned call "
+                             "by call to a recording of the reference (tests/test_decode_trace.py)")
+                    if args.mode == "graph":          # the fused step launched eagerly: what the call order is compared with
+                        r = run_decode(model, clone_args(args, mode="eager"), ctx, short["steps"], short["warmup"], args.walk_step,
+                                       seed=99 + rank)
+                        extras["value_eager"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                     chunk_hit_rate=round(r["hit_rate"], 4), steps=short["steps"],
+                                                     note="--mode eager: the fused 9-launch step issued from Python every step (no hipGraph)")
+                        extras["value_call_order"]["fraction_of_eager_fused"] = round(extras["value_call_order"]["value"] / r["value"], 3)
+                if ref_set and args.layout == "inplace" and args.query_mode == "walk":
+                    extras["fetch_launch"] = measure_fetch_launch(model, ctx, args.walk_step)
+                try:     # which branch of the fused selection the heads took in the last step, over all layers
+                    fs = [cache.fused_select_stats(l) for l in range(model.num_layers)]
+                    if fs[0] is not None:
+                        st = torch.cat(fs)
+                        nh = st.shape[0]
+                        extras["fused_select"] = dict(
+                            heads=nh, level_held=int((st[:, 0] == 0).sum()), level_searched=int(((st[:, 0] & 1) != 0).sum()),
+                            every_slot_evaluated=int(((st[:, 0] & 2) != 0).sum()), mean_candidates=round(float(st[:, 1].float().mean()), 1),
+                            max_candidates=int(st[:, 1].max()), select_sets=cache.select_sets,
+                            note="(layer, KV head) pairs of the last decode step run on this state (same query walk as the timed run); results are identical on every branch")
                 except Exception as e:
-                    print(f"[bench] early-fetch statistics failed: {e}", file=sys.stderr)
-                near_rec = None
-                if cache.near_fetch:       # the same captured run with the in-step early fetch alone (no near-miss staging)
-                    cache.near_fetch = False
-                    rn = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
-                    cache.near_fetch = True
-                    near_rec = dict(slots_per_head=64, pull_workgroups_per_head=cache.near_pull_parts or max(1, min(4, 8 // cache.block_num)),
-                                    value_without=dict(value=round(rn["value"], 2), ms_per_step=round(rn["ms_per_step"], 4), steps=short["steps"]),
-                                    note="near-miss staging ahead of the next step (round 5, csrc/skv_early.h skv_near_pull_role): the gate/up "
-                                         "GEMV launch of every layer stages the chunks that fell just short of the step's selection; "
-                                         "identical results, chunk hit rate and resident policy untouched (profiles/r05_near_fetch.txt)")
-                cache._early = None
-                r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
-                cache._early = ea
-                if near_rec is not None:
-                    extras["near_fetch"] = near_rec
-                extras["early_fetch"] = dict(
-                    chunks_per_head=ea["E"], margin=ea["margin"],
-                    last_layer_one_step=None if stats is None else dict(pulled_early=stats[0], read_from_staging=stats[1], misses=stats[2]),
-                    value_without=dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]),
-                    note="speculative early V fetch (csrc/skv_early.h): chunks predicted to miss are pulled over PCIe by an extra "
-                         "workgroup of the top-k launch; identical results (tests/test_gpu_kv_cache.py)")
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
-        if os.path.exists(pmc_path) and args.workload == "llama31_122k" and bs == 1:
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": (HEADLINE_METRIC if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}")
-            if not full else f"decode tokens/sec, FULL-ATTENTION baseline, {args.workload}",
-            "value": round(head["value"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
-                                   f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}{'' if full or cache.resident_sets == cache.select_sets else f', {cache.resident_sets} resident chunk slots per head (LRU; NOT the reference resident set)'}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
-                                   + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)")
-                                   + ("" if args.pin_hit_rate is None else f" (chunk hit rate pinned to {args.pin_hit_rate})"),
-                       "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
-            "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
-            "launch_mode": head["mode"], "early_fetch_chunks_per_head": None if full or cache._early is None else cache._early["E"],
-            "near_fetch": bool(not full and cache._early is not None and getattr(cache, "near_fetch", False)),
-            "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
-            "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa, "per_rank": per_rank,
-            "parity_note": "selection path bit-exact against the CPU oracle; top-k stage pinned to the reference's torch.topk "
-                           "(set-equal modulo ties); scoring vs the reference's CUTLASS softmax is pinned by bound only "
-                           "(parity unpinned: un-vendored CUTLASS), K rebuild by tolerance (MFMA accumulation order)",
-        }
-        if roof is not None:
-            # two durations of the same launch: HIP events around back-to-back launches measured live in THIS run, and the
-            # in-step average rocprofv3 recorded inside captured decode steps (profiles/score_kernel_in_step.json, written by
-            # tools/prof.sh from the steady-state window of the same bench command).  In a step the launch starts cold behind
-            # another kernel and is ~0.5 us longer: `achieved` / `frac` are computed from the in-step figure when the profile
-            # is of this kernel and workload, the live figure is reported beside it.
-            in_step = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "score_kernel_in_step.json")) as f:
-                    rec = json.load(f)
-                if rec.get("workload") == args.workload and roof["kernel"] in rec.get("kernel", ""):
-                    in_step = rec
-            except (OSError, ValueError):
-                pass
-            us_live = roof["us_per_launch"]
-            us_roof = in_step["us_per_launch_in_step"] if in_step else us_live
-            gbs = roof["algorithmic_bytes"] / (us_roof * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; collected by tools/pmc_score.sh on the fused-selection form of the launch, a separate profiled run - not re-measured inside this run)",
-                               "kernel": roof["kernel"], "launch_form": roof.get("launch"),
-                               "duration_used": "in_step (rocprofv3)" if in_step else "hip_events_back_to_back (this run)",
-                               "us_per_launch": round(us_live, 3), "us_per_launch_in_step": None if in_step is None else in_step["us_per_launch_in_step"],
-                               "in_step_source": None if in_step is None else f"profiles/score_kernel_in_step.json: {in_step.get('launches')} launches inside {in_step.get('steps')} captured steps, {in_step.get('source')}",
-                               "frac_hip_events": round(roof["gbs"] / HBM_PEAK_GBS, 4),
-                               "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
-        out.update(extras)
-        if bs == 24 and args.workload == "llama31_122k" and not full:
-            # context only (other hardware, the reference's own batch regime): never a vs_baseline
-            out["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100", "batch": 24,
-                                                     "source": "index.html:210-214 (config test/e2e.py:63-68)"}
-        if world == 1 and bs == 1 and not full and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, args.walk_step)
-        if detail and not args.no_secondary and args.workload == "llama31_122k" and bs == 1 and args.layers is None:
-            import gc
-            sec = []
-            # BASELINE.json configs 2 and 3, then the reference's other regimes (test/e2e.py:35-116: budget 4096 at 244K, budget
-            # 1024 at 60K, and Yi-9B-200K = G 8 with NeoX RoPE); short runs
-            for wl in ("llama3_1048k_131072", "glm4_200k", "llama31_244k_b4096", "llama31_60k_b1024", "yi9b_122k"):
-                model = cache = None
-                gc.collect(); torch.cuda.empty_cache()
-                model, cfg2, ctx2, budget2, tb = build_model(wl, args, rank, dev)
-                r = run_decode(model, args, ctx2, 24, 4, args.walk_step, seed=99 + rank)
-                rf = measure_score_kernel(model)          # the landmark scan of THIS workload's shape against the HBM roof
-                sec.append(dict(name=wl, workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
-                                path="in-place layout, attention inside the fetch launch" if model.kv_cache.can_overlap_attention() else "plain fetch launch + standalone attention",
-                                early_fetch_chunks_per_head=None if model.kv_cache._early is None else model.kv_cache._early["E"],
-                                near_fetch=bool(model.kv_cache._early is not None and model.kv_cache.near_fetch),
-                                value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1),
-                                scan_roofline={"us_per_launch": round(rf["us_per_launch"], 3), "algorithmic_bytes_per_launch": rf["algorithmic_bytes"],
-                                               "achieved": round(rf["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                               "frac": round(rf["gbs"] / HBM_PEAK_GBS, 4)}))
-            out["secondary"] = sec
-            # the same workload with 512 resident chunk slots per head (HBM is plentiful, the link is the roof): identical
-            # selections and outputs, fewer chunks over PCIe.  Not the headline: the reference's resident set is the last
-            # selection (256 slots).
-            if args.resident_sets is None and args.layout == "inplace" and args.mode == "graph":
-                model = cache = None
-                gc.collect(); torch.cuda.empty_cache()
-                model, _, ctx3, _, tb = build_model(args.workload, args, rank, dev, resident_sets=512)
-                r = run_decode(model, args, ctx3, 32, 12, args.walk_step, seed=99 + rank)
-                out["value_resident_512"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                                 chunk_hit_rate=round(r["hit_rate"], 4), steps=32, warmup=12,
-                                                 note="--resident-sets 512: least-recently-selected replacement over 512 "
-                                                      "slots per head, attention over the 256 selected chunks as before")
-        default_line = (detail and args.workload == "llama31_122k" and bs == 1 and args.layers is None and args.mode == "graph"
-                        and args.layout == "inplace" and args.resident_sets is None and args.v_table == "host")
-        if default_line:
-            model = cache = None
-            free_model()
-            try:
-                out["prefill_state_ms_per_layer"] = measure_prefill_state(args.workload, dev)
-            except Exception as e:           # a diagnostic entry must not cost the line
-                out["prefill_state_ms_per_layer"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
-            free_model()
-        best_batched = None
-        if default_line and not args.no_batched:
-            # the reference's own regime (test/e2e.py:63-68, index.html:210-214: bs 24 at 122K on an A100 = 245.90 tok/s):
-            # sequences per GPU > 1, V in pinned host memory, captured step
-            out["batched"] = []
-            for b in [int(x) for x in args.batched.split(",") if x]:
-                model = cache = None
-                free_model()
-                a2 = clone_args(args, batch=b)
-                try:
-                    model, _, ctxb, _, tb = build_model(args.workload, a2, rank, dev)
-                except (MemoryError, RuntimeError) as e:          # e.g. the 197 GB pinned V table of bs 24 does not fit the box
-                    out["batched"].append(dict(batch=b, skipped=f"{type(e).__name__}: {str(e)[:200]}"))
-                    model = None
-                    continue
-                r = run_decode(model, a2, ctxb, 16, 4, args.walk_step, seed=99 + rank)
-                ent = dict(batch=b, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                           chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4, launch_mode=r["mode"],
-                           state_build_s=round(tb, 1), v_table="pinned host memory",
-                           fetch_launch=measure_fetch_launch(model, ctxb, args.walk_step, steps=2))
-                if not args.no_batched_resident:
-                    # the same batch with 512 resident chunk slots per head (NOT the reference's policy - its resident set is the last
-                    # selection, 256 slots): identical selections and outputs, fewer chunks over the link the batch sits on
+                    print(f"[bench] fused-selection statistics failed: {e}", file=sys.stderr)
+                if cache._early is not None and args.mode == "graph":
+                    # the speculative early V fetch: what it pulled / what the fetch launch then read from staging (last layer of
+                    # one more eager step), and the same captured run without it
+                    from shadowkv_amd import llama
+                    ea = cache._early
+                    stats = None
                     try:
-                        model = cache = None
-                        free_model()
-                        model, _, ctxr, _, tbr = build_model(args.workload, a2, rank, dev, resident_sets=512)
-                        rr = run_decode(model, a2, ctxr, 16, 4, args.walk_step, seed=99 + rank)
-                        ent["resident_512"] = dict(value=round(rr["value"], 2), ms_per_step=round(rr["ms_per_step"], 4),
-                                                   chunk_hit_rate=round(rr["hit_rate"], 4), steps=16, warmup=4, state_build_s=round(tbr, 1),
-                                                   note="--resident-sets 512: least-recently-selected replacement over 512 slots per head; "
-                                                        "not the reference's resident set, not the headline")
-                    except (MemoryError, RuntimeError) as e:
-                        ent["resident_512"] = dict(skipped=f"{type(e).__name__}: {str(e)[:200]}")
-                if b == 24:
-                    ent["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100",
-                                                             "source": "index.html:210-214 (config test/e2e.py:63-68)",
-                                                             "note": "other hardware: context only, never a vs_baseline"}
-                out["batched"].append(ent)
-                if best_batched is None or ent["value"] > best_batched["value"]:
-                    best_batched = ent
-        if default_line and not args.no_pair:
-            # e2e-style pair (test/e2e.py:140-168): full attention at the largest batch whose KV cache fits the GPU against
-            # ShadowKV at its own largest measured batch
-            model = cache = None
-            free_model()
-            cfg1 = WORKLOADS[args.workload]
-            free_b, _ = torch.cuda.mem_get_info()
-            from shadowkv_amd import llama as _ll
-            c1 = getattr(_ll, cfg1[0])
-            per_seq = 2 * c1.num_hidden_layers * c1.num_key_value_heads * (cfg1[1] + 1024) * 128 * 2
-            b_full = int((free_b - c1.vocab_size * c1.hidden_size * 4 - 15.2e9 - 8e9) // per_seq)
-            pair = dict(note="test/e2e.py:140-168 style: full attention at the largest batch whose KV cache fits HBM vs "
-                             "ShadowKV at its largest measured batch, same kernels for the dense layers")
-            if b_full >= 1:
-                a3 = clone_args(args, batch=b_full, attn="full")
-                model, _, ctxf, _, tb = build_model(args.workload, a3, rank, dev)
-                r = run_decode(model, a3, ctxf, 8, 2, args.walk_step, seed=99 + rank)
-                pair["full_attention"] = dict(batch=b_full, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                              steps=8, warmup=2, kv_cache_gb=round(per_seq * b_full / 1e9, 1), state_build_s=round(tb, 1))
-                model = None
+                        rewind(model, ctx)
+                        walk2 = llama.QueryWalk(model, step=args.walk_step, seed=99 + rank)
+                        tok2 = torch.randint(0, cfg.vocab_size, (bs, 1), device=dev)
+                        for _ in range(4):
+                            walk2.advance()
+                            tok2 = model.decode_step(tok2, temperature=0.6, q_table=walk2.qb)
+                        torch.cuda.synchronize()
+                        stats = cache.early_fetch_stats(model.num_layers - 1)
+                    except Exception as e:
+                        print(f"[bench] early-fetch statistics failed: {e}", file=sys.stderr)
+                    near_rec = None
+                    if cache.near_fetch:       # the same captured run with the in-step early fetch alone (no near-miss staging)
+                        cache.near_fetch = False
+                        rn = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                        cache.near_fetch = True
+                        near_rec = dict(slots_per_head=64, pull_workgroups_per_head=cache.near_pull_parts or max(1, min(4, 8 // cache.block_num)),
+                                        value_without=dict(value=round(rn["value"], 2), ms_per_step=round(rn["ms_per_step"], 4), steps=short["steps"]),
+                                        note="near-miss staging ahead of the next step (round 5, csrc/skv_early.h skv_near_pull_role): the gate/up "
+                                             "GEMV launch of every layer stages the chunks that fell just short of the step's selection; "
+                                             "identical results, chunk hit rate and resident policy untouched (profiles/r05_near_fetch.txt)")
+                    cache._early = None
+                    r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
+                    cache._early = ea
+                    if near_rec is not None:
+                        extras["near_fetch"] = near_rec
+                    extras["early_fetch"] = dict(
+                        chunks_per_head=ea["E"], margin=ea["margin"],
+                        last_layer_one_step=None if stats is None else dict(pulled_early=stats[0], read_from_staging=stats[1], misses=stats[2]),
+                        value_without=dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4), steps=short["steps"]),
+                        note="speculative early V fetch (csrc/skv_early.h): chunks predicted to miss are pulled over PCIe by an extra "
+                             "workgroup of the top-k launch; identical results (tests/test_gpu_kv_cache.py)")
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
+            if os.path.exists(pmc_path) and args.workload == "llama31_122k" and bs == 1:
+                try:
+                    traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out = {
+                "metric": (HEADLINE_METRIC if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}")
+                if not full else f"decode tokens/sec, FULL-ATTENTION baseline, {args.workload}",
+                "value": round(head["value"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, "
+                                       f"chunk_size 8, bs {bs} per GPU, {model.num_layers} layers, chunk layout {args.layout}{'' if full or cache.resident_sets == cache.select_sets else f', {cache.resident_sets} resident chunk slots per head (LRU; NOT the reference resident set)'}, V table in {'pinned host memory' if args.v_table == 'host' else 'HBM (NOT the headline configuration)'}"
+                                       + ("" if args.layers is None else " (REDUCED LAYERS: not a valid result)")
+                                       + ("" if args.pin_hit_rate is None else f" (chunk hit rate pinned to {args.pin_hit_rate})"),
+                           "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"},
+                "chunk_hit_rate": None if head["hit_rate"] is None else round(head["hit_rate"], 4),
+                "launch_mode": head["mode"], "early_fetch_chunks_per_head": None if full or cache._early is None else cache._early["E"],
+                "near_fetch": bool(not full and cache._early is not None and getattr(cache, "near_fetch", False)),
+                "slack_ring": head["slack_ring"], "query_mode": args.query_mode,
+                "walk_step": args.walk_step, "state_build_s": round(t_build, 1), "numa_node": numa, "per_rank": per_rank,
+                "parity_note": "selection path bit-exact against the CPU oracle; top-k stage pinned to the reference's torch.topk "
+                               "(set-equal modulo ties); scoring vs the reference's CUTLASS softmax is pinned by bound only "
+                               "(parity unpinned: un-vendored CUTLASS), K rebuild by tolerance (MFMA accumulation order)",
+            }
+            if roof is not None:
+                # two durations of the same launch: HIP events around back-to-back launches measured live in THIS run, and the
+                # in-step average rocprofv3 recorded inside captured decode steps (profiles/score_kernel_in_step.json, written by
+                # tools/prof.sh from the steady-state window of the same bench command).  In a step the launch starts cold behind
+                # another kernel and is ~0.5 us longer: `achieved` / `frac` are computed from the in-step figure when the profile
+                # is of this kernel and workload, the live figure is reported beside it.
+                in_step = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "score_kernel_in_step.json")) as f:
+                        rec = json.load(f)
+                    if rec.get("workload") == args.workload and roof["kernel"] in rec.get("kernel", ""):
+                        in_step = rec
+                except (OSError, ValueError):
+                    pass
+                us_live = roof["us_per_launch"]
+                us_roof = in_step["us_per_launch_in_step"] if in_step else us_live
+                gbs = roof["algorithmic_bytes"] / (us_roof * 1e-6) / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                   "traffic_source": "profiles/score_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction; collected by tools/pmc_score.sh on the fused-selection form of the launch, a separate profiled run - not re-measured inside this run)",
+                                   "kernel": roof["kernel"], "launch_form": roof.get("launch"),
+                                   "duration_used": "in_step (rocprofv3)" if in_step else "hip_events_back_to_back (this run)",
+                                   "us_per_launch": round(us_live, 3), "us_per_launch_in_step": None if in_step is None else in_step["us_per_launch_in_step"],
+                                   "in_step_source": None if in_step is None else f"profiles/score_kernel_in_step.json: {in_step.get('launches')} launches inside {in_step.get('steps')} captured steps, {in_step.get('source')}",
+                                   "frac_hip_events": round(roof["gbs"] / HBM_PEAK_GBS, 4),
+                                   "algorithmic_bytes_per_launch": roof["algorithmic_bytes"]}
+            out.update(extras)
+            if bs == 24 and args.workload == "llama31_122k" and not full:
+                # context only (other hardware, the reference's own batch regime): never a vs_baseline
+                out["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100", "batch": 24,
+                                                         "source": "index.html:210-214 (config test/e2e.py:63-68)"}
+            if world == 1 and bs == 1 and not full and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(model, args.walk_step)
+            if detail and not args.no_secondary and args.workload == "llama31_122k" and bs == 1 and args.layers is None:
+                import gc
+                sec = []
+                # BASELINE.json configs 2 and 3, then the reference's other regimes (test/e2e.py:35-116: budget 4096 at 244K, budget
+                # 1024 at 60K, and Yi-9B-200K = G 8 with NeoX RoPE); short runs
+                for wl in ("llama3_1048k_131072", "glm4_200k", "llama31_244k_b4096", "llama31_60k_b1024", "yi9b_122k"):
+                    model = cache = None
+                    gc.collect(); torch.cuda.empty_cache()
+                    model, cfg2, ctx2, budget2, tb = build_model(wl, args, rank, dev)
+                    r = run_decode(model, args, ctx2, 24, 4, args.walk_step, seed=99 + rank)
+                    rf = measure_score_kernel(model)          # the landmark scan of THIS workload's shape against the HBM roof
+                    sec.append(dict(name=wl, workload=f"{cfg2.name} decode, context {ctx2} tokens, sparse_budget {budget2}, rank 160, chunk_size 8, bs 1, {model.num_layers} layers",
+                                    path="in-place layout, attention inside the fetch launch" if model.kv_cache.can_overlap_attention() else "plain fetch launch + standalone attention",
+                                    early_fetch_chunks_per_head=None if model.kv_cache._early is None else model.kv_cache._early["E"],
+                                    near_fetch=bool(model.kv_cache._early is not None and model.kv_cache.near_fetch),
+                                    value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                    chunk_hit_rate=round(r["hit_rate"], 4), steps=24, warmup=4, state_build_s=round(tb, 1),
+                                    scan_roofline={"us_per_launch": round(rf["us_per_launch"], 3), "algorithmic_bytes_per_launch": rf["algorithmic_bytes"],
+                                                   "achieved": round(rf["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(rf["gbs"] / HBM_PEAK_GBS, 4)}))
+                out["secondary"] = sec
+                # the same workload with 512 resident chunk slots per head (HBM is plentiful, the link is the roof): identical
+                # selections and outputs, fewer chunks over PCIe.  Not the headline: the reference's resident set is the last
+                # selection (256 slots).
+                if args.resident_sets is None and args.layout == "inplace" and args.mode == "graph":
+                    model = cache = None
+                    gc.collect(); torch.cuda.empty_cache()
+                    model, _, ctx3, _, tb = build_model(args.workload, args, rank, dev, resident_sets=512)
+                    r = run_decode(model, args, ctx3, 32, 12, args.walk_step, seed=99 + rank)
+                    out["value_resident_512"] = dict(value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                     chunk_hit_rate=round(r["hit_rate"], 4), steps=32, warmup=12,
+                                                     note="--resident-sets 512: least-recently-selected replacement over 512 "
+                                                          "slots per head, attention over the 256 selected chunks as before")
+            default_line = (detail and args.workload == "llama31_122k" and bs == 1 and args.layers is None and args.mode == "graph"
+                            and args.layout == "inplace" and args.resident_sets is None and args.v_table == "host")
+            if default_line:
+                model = cache = None
                 free_model()
-                # ShadowKV with the chunked V table in HBM at bs 16 (fits 288 GB; NOT the north-star layout: V is not offloaded)
-                a4 = clone_args(args, batch=16, v_table="hbm")
-                model, _, ctxh, _, tb = build_model(args.workload, a4, rank, dev)
-                r = run_decode(model, a4, ctxh, 16, 4, args.walk_step, seed=99 + rank)
-                pair["shadowkv_v_in_hbm_bs16"] = dict(batch=16, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
-                                                      chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4,
-                                                      note="--v-table hbm: V chunks in HBM instead of pinned host memory "
-                                                           "(MI355X fits it, the A100 could not); not the north-star layout")
-                model = None
+                try:
+                    out["prefill_state_ms_per_layer"] = measure_prefill_state(args.workload, dev)
+                except Exception as e:           # a diagnostic entry must not cost the line
+                    out["prefill_state_ms_per_layer"] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
                 free_model()
-            if best_batched is not None:
-                pair["shadowkv"] = dict(batch=best_batched["batch"], value=best_batched["value"], ms_per_step=best_batched["ms_per_step"])
-                if "full_attention" in pair:
-                    pair["ratio"] = round(best_batched["value"] / pair["full_attention"]["value"], 3)
-            out["speedup_vs_full_attention"] = pair
+            best_batched = None
+            if default_line and not args.no_batched:
+                # the reference's own regime (test/e2e.py:63-68, index.html:210-214: bs 24 at 122K on an A100 = 245.90 tok/s):
+                # sequences per GPU > 1, V in pinned host memory, captured step
+                out["batched"] = []
+                for b in [int(x) for x in args.batched.split(",") if x]:
+                    model = cache = None
+                    free_model()
+                    a2 = clone_args(args, batch=b)
+                    try:
+                        model, _, ctxb, _, tb = build_model(args.workload, a2, rank, dev)
+                    except (MemoryError, RuntimeError) as e:          # e.g. the 197 GB pinned V table of bs 24 does not fit the box
+                        out["batched"].append(dict(batch=b, skipped=f"{type(e).__name__}: {str(e)[:200]}"))
+                        model = None
+                        continue
+                    r = run_decode(model, a2, ctxb, 16, 4, args.walk_step, seed=99 + rank)
+                    ent = dict(batch=b, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                               chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4, launch_mode=r["mode"],
+                               state_build_s=round(tb, 1), v_table="pinned host memory",
+                               fetch_launch=measure_fetch_launch(model, ctxb, args.walk_step, steps=2))
+                    if not args.no_batched_resident:
+                        # the same batch with 512 resident chunk slots per head (NOT the reference's policy - its resident set is the last
+                        # selection, 256 slots): identical selections and outputs, fewer chunks over the link the batch sits on
+                        try:
+                            model = cache = None
+                            free_model()
+                            model, _, ctxr, _, tbr = build_model(args.workload, a2, rank, dev, resident_sets=512)
+                            rr = run_decode(model, a2, ctxr, 16, 4, args.walk_step, seed=99 + rank)
+                            ent["resident_512"] = dict(value=round(rr["value"], 2), ms_per_step=round(rr["ms_per_step"], 4),
+                                                       chunk_hit_rate=round(rr["hit_rate"], 4), steps=16, warmup=4, state_build_s=round(tbr, 1),
+                                                       note="--resident-sets 512: least-recently-selected replacement over 512 slots per head; "
+                                                            "not the reference's resident set, not the headline")
+                        except (MemoryError, RuntimeError) as e:
+                            ent["resident_512"] = dict(skipped=f"{type(e).__name__}: {str(e)[:200]}")
+                    if b == 24:
+                        ent["reference_published_same_batch"] = {"value": 245.90, "unit": "tokens/s", "hardware": "1x A100",
+                                                                 "source": "index.html:210-214 (config test/e2e.py:63-68)",
+                                                                 "note": "other hardware: context only, never a vs_baseline"}
+                    out["batched"].append(ent)
+                    if best_batched is None or ent["value"] > best_batched["value"]:
+                        best_batched = ent
+            if default_line and not args.no_pair:
+                # e2e-style pair (test/e2e.py:140-168): full attention at the largest batch whose KV cache fits the GPU against
+                # ShadowKV at its own largest measured batch
+                model = cache = None
+                free_model()
+                cfg1 = WORKLOADS[args.workload]
+                free_b, _ = torch.cuda.mem_get_info()
+                from shadowkv_amd import llama as _ll
+                c1 = getattr(_ll, cfg1[0])
+                per_seq = 2 * c1.num_hidden_layers * c1.num_key_value_heads * (cfg1[1] + 1024) * 128 * 2
+                b_full = int((free_b - c1.vocab_size * c1.hidden_size * 4 - 15.2e9 - 8e9) // per_seq)
+                pair = dict(note="test/e2e.py:140-168 style: full attention at the largest batch whose KV cache fits HBM vs "
+                                 "ShadowKV at its largest measured batch, same kernels for the dense layers")
+                if b_full >= 1:
+                    a3 = clone_args(args, batch=b_full, attn="full")
+                    model, _, ctxf, _, tb = build_model(args.workload, a3, rank, dev)
+                    r = run_decode(model, a3, ctxf, 8, 2, args.walk_step, seed=99 + rank)
+                    pair["full_attention"] = dict(batch=b_full, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                  steps=8, warmup=2, kv_cache_gb=round(per_seq * b_full / 1e9, 1), state_build_s=round(tb, 1))
+                    model = None
+                    free_model()
+                    # ShadowKV with the chunked V table in HBM at bs 16 (fits 288 GB; NOT the north-star layout: V is not offloaded)
+                    a4 = clone_args(args, batch=16, v_table="hbm")
+                    model, _, ctxh, _, tb = build_model(args.workload, a4, rank, dev)
+                    r = run_decode(model, a4, ctxh, 16, 4, args.walk_step, seed=99 + rank)
+                    pair["shadowkv_v_in_hbm_bs16"] = dict(batch=16, value=round(r["value"], 2), ms_per_step=round(r["ms_per_step"], 4),
+                                                          chunk_hit_rate=round(r["hit_rate"], 4), steps=16, warmup=4,
+                                                          note="--v-table hbm: V chunks in HBM instead of pinned host memory "
+                                                               "(MI355X fits it, the A100 could not); not the north-star layout")
+                    model = None
+                    free_model()
+                if best_batched is not None:
+                    pair["shadowkv"] = dict(batch=best_batched["batch"], value=best_batched["value"], ms_per_step=best_batched["ms_per_step"])
+                    if "full_attention" in pair:
+                        pair["ratio"] = round(best_batched["value"] / pair["full_attention"]["value"], 3)
+                out["speedup_vs_full_attention"] = pair
+        except Exception as e:      # noqa: BLE001 - see above
+            import traceback
+            traceback.print_exc()
+            if out is None:
+                out = {"metric": HEADLINE_METRIC if args.workload == "llama31_122k" else f"decode tokens/sec, {args.workload}",
+                       "value": round(head["value"], 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                       "dtype": "bf16", "data": "synthetic",
+                       "config": {"workload": f"{cfg.name} decode, context {ctx} tokens, sparse_budget {budget}, rank 160, chunk_size 8, bs {bs} per GPU",
+                                  "parallelism": f"replicas x{world} (1 sequence / GPU, no collectives on the decode path)"}}
+            out["bench_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -127,6 +127,8 @@ def _stub_bench(bench, rank):
 
     def measure_score_kernel(model_, iters=3):
         calls["score"] += 1
+        if os.environ.get("SKV_TEST_BREAK_SCORE"):
+            raise RuntimeError("a reporting leg broke")
         return dict(kernel="stub", us_per_launch=8.0, algorithmic_bytes=32_000_000, gbs=4000.0)
 
     bench.DIST_BACKEND = "gloo"
@@ -203,6 +205,19 @@ def test_plain_bench_returns_the_worst_child_exit_code():
     """A rank that dies must not leave the other waiting in a barrier: the launcher stops it and reports the failure."""
     r = _plain_bench({"SKV_TEST_FAIL_RANK": "1"})
     assert r.returncode == 7 and r.stdout.strip() == "" and "rank 1 exited with code 7" in r.stderr
+
+
+def test_a_failing_reporting_leg_still_leaves_the_line():
+    """Everything behind the timed headline runs guarded: a leg that raises is reported in the line (`bench_error`), the headline
+    value is still printed and the exit code stays 0."""
+    import json
+    r = _plain_bench({"SKV_TEST_BREAK_SCORE": "1"})
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] == 2 * 10 / 1.0 and rec["n_gpus"] == 2 and "a reporting leg broke" in rec["bench_error"]
+    assert "Traceback" in r.stderr
 
 
 def test_launcher_form_with_a_wrong_world_size_is_refused():
