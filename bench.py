@@ -1106,7 +1106,7 @@ def main(argv=None):
                     r = run_decode(model, args, ctx, short["steps"], short["warmup"], args.walk_step, seed=99 + rank)
                     cache._early = ea
                     if near_rec is not None:
-                        extras["near_fetch"] = near_rec
+                        extras["near_miss_staging"] = near_rec
                     extras["early_fetch"] = dict(
                         chunks_per_head=ea["E"], margin=ea["margin"],
                         last_layer_one_step=None if stats is None else dict(pulled_early=stats[0], read_from_staging=stats[1], misses=stats[2]),
