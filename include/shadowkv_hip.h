@@ -496,8 +496,10 @@ SKV_EXPORT int skv_sample_topk_advance(const void* logits, long long row_stride,
 SKV_EXPORT int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
                                             void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
                                             int n_landmarks, int n_chunks, int early_max, const void* v_host,
-                                            long long host_block_stride, int pull_parts, skv_stream_t stream);
-/* The same role for near-miss list `list` (0: the 64 candidates just below the selection, what the call above stages; 1: the next
+                                            long long host_block_stride, int pull_parts, int active_lists, skv_stream_t stream);
+/* (active_lists: 1 = only this launch stages - the default; 2 = skv_gemv_near_pull_bf16 stages list 1 as well: each role then keeps a
+ * chunk either list wants and does not pull what the other one holds.)
+ * The same role for near-miss list `list` (0: the 64 candidates just below the selection, what the call above stages; 1: the next
  * 64, staging slots early_max + 64 ..) in a plain one-token GEMV launch with N <= 8192 rows - skv_gemv_bf16, the layer's down
  * projection (bias: the residual riding in the bias slot, or NULL).  Same GEMV result. */
 SKV_EXPORT int skv_gemv_near_pull_bf16(const void* W, const void* x, const void* bias, void* y, int N, int K, void* early_state,

@@ -74,7 +74,7 @@ _SIGS = {
     "skv_update_kv_cache": (c_int, [c_p] * 4 + [c_int] * 4 + [c_ll] * 8 + [c_int] * 2 + [c_p]),
     "skv_norm_gemv_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 3 + [c_int] * 3 + [c_p]),
     "skv_norm_gemv_rangemax_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 3 + [c_int] * 2 + [c_p, c_p]),
-    "skv_norm_gemv_near_pull_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 2 + [c_int] * 2 + [c_p] + [c_int] * 5 + [c_p, c_ll, c_int, c_p]),
+    "skv_norm_gemv_near_pull_bf16": (c_int, [c_p] * 4 + [c_f] + [c_p] * 2 + [c_int] * 2 + [c_p] + [c_int] * 5 + [c_p, c_ll, c_int, c_int, c_p]),
     "skv_gemv_near_pull_bf16": (c_int, [c_p] * 4 + [c_int] * 2 + [c_p] + [c_int] * 5 + [c_p, c_ll, c_int, c_int, c_p]),
     "skv_qkv_gemv_rope_update": (c_int, [c_p] * 4 + [c_f] + [c_p] * 9 + [c_int] * 4 + [c_ll, c_int, c_ll] + [c_int] * 2 + [c_p]),
     "skv_gemv_bf16": (c_int, [c_p] * 4 + [c_int] * 3 + [c_p]),

@@ -303,9 +303,9 @@ __device__ __forceinline__ void skv_near_pull_role(const NearPull& np, int blk, 
             const int o = np.near_pub[(size_t)b * NL + slot0 + tid];
             s_old[tid] = (o >= 0 && o < n_chunks) ? o : -1;
         }
-        const int ocnt = min(max(np.other_cnt[b], 0), NL);
-        s_onew[tid] = tid < ocnt ? np.other_ids[(size_t)b * NL + tid] : -1;
-        s_opub[tid] = np.other_pub[(size_t)b * NL + tid];
+        const int ocnt = np.other_cnt != nullptr ? min(max(np.other_cnt[b], 0), NL) : 0;
+        s_onew[tid] = tid < ocnt ? np.other_ids[(size_t)b * NL + tid] : -2;      // (-2: matches no id and no empty slot)
+        s_opub[tid] = np.other_pub != nullptr ? np.other_pub[(size_t)b * NL + tid] : -2;
     }
     __syncthreads();
     if (tid < NL) {                       // wave 0

@@ -370,24 +370,25 @@ extern "C" int skv_norm_gemv_bf16(const void* W, const void* x, const void* resi
 }
 
 static int near_pull_of(NearPull& np, void* early_state, int blocks, int groups, int n_landmarks, int n_chunks, int early_max,
-                        const void* v_host, long long host_block_stride, int pull_parts, int list) {
+                        const void* v_host, long long host_block_stride, int pull_parts, int list, int active_lists) {
     if (pull_parts != 1 && pull_parts != 2 && pull_parts != 4) return SKV_ERR_ARG;
-    if (list < 0 || list >= SKV_NEAR_LISTS) return SKV_ERR_ARG;
+    if (list < 0 || list >= SKV_NEAR_LISTS || active_lists < 1 || active_lists > SKV_NEAR_LISTS || list >= active_lists) return SKV_ERR_ARG;
     if (!early_state || !v_host || blocks < 1 || groups < 1 || n_landmarks < 1 || n_chunks < 1 || early_max < 1 || early_max > 128 ||
         (host_block_stride % 8))
         return SKV_ERR_ARG;
     if (n_chunks > (1 << 18)) return SKV_ERR_UNSUPPORTED;      // (the early state's limit, skv_select_chunks_fused)
     const EarlyState es = skv_carve_early(early_state, blocks, groups, n_landmarks, n_chunks, early_max);
-    np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max, pull_parts, list);
+    np = skv_near_pull(es, v_host, host_block_stride, blocks, n_chunks, early_max, pull_parts, list, active_lists);
     return SKV_OK;
 }
 
 extern "C" int skv_norm_gemv_near_pull_bf16(const void* W, const void* x, const void* residual, const void* norm_weight, float eps,
                                             void* h_out, void* y, int N, int K, void* early_state, int blocks, int groups,
                                             int n_landmarks, int n_chunks, int early_max, const void* v_host,
-                                            long long host_block_stride, int pull_parts, skv_stream_t stream) {
+                                            long long host_block_stride, int pull_parts, int active_lists, skv_stream_t stream) {
     NearPull np{};
-    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, 0);
+    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, 0,
+                                active_lists);
     if (rc != SKV_OK) return rc;
     return launch_gemv(W, x, nullptr, y, N, K, 1, residual, norm_weight, h_out, eps, true, (hipStream_t)stream, nullptr, nullptr, &np);
 }
@@ -397,7 +398,8 @@ extern "C" int skv_gemv_near_pull_bf16(const void* W, const void* x, const void*
                                        int blocks, int groups, int n_landmarks, int n_chunks, int early_max, const void* v_host,
                                        long long host_block_stride, int pull_parts, int list, skv_stream_t stream) {
     NearPull np{};
-    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, list);
+    const int rc = near_pull_of(np, early_state, blocks, groups, n_landmarks, n_chunks, early_max, v_host, host_block_stride, pull_parts, list,
+                                SKV_NEAR_LISTS);
     if (rc != SKV_OK) return rc;
     return launch_gemv(W, x, bias, y, N, K, 0, nullptr, nullptr, nullptr, 0.f, false, (hipStream_t)stream, nullptr, nullptr, &np);
 }

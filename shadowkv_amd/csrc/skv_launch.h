@@ -184,12 +184,15 @@ struct NearPull {
     int n_chunks, E, parts;
     int slot_base;              // first staging slot of the list behind E: 64 * list
     // the OTHER list (staged by another launch of the same step): a chunk it holds is not pulled again, a chunk it wants is kept
-    const int* other_cnt;       // [B]
+    const int* other_cnt;       // [B]   (all three null: only this list is staged)
     const int* other_ids;       // [B][SKV_NEAR_MAX]
     const int* other_pub;       // [B][SKV_NEAR_MAX]
 };
 static inline NearPull skv_near_pull(const EarlyState& es, const void* v_host, long long host_block_stride, int B, int n_chunks, int E,
-                                     int parts, int list) {
+                                     int parts, int list, int active_lists) {
+    if (active_lists < 2)       // the other list is not staged by anybody: nothing of it to keep or to skip
+        return NearPull{es.near_cnt + (size_t)list * B, es.near_ids + (size_t)list * B * SKV_NEAR_MAX, es.near_pub + (size_t)list * B * SKV_NEAR_MAX,
+                        es.early_of, es.staging, v_host, host_block_stride / 8, B * parts, n_chunks, E, parts, 64 * list, nullptr, nullptr, nullptr};
     return NearPull{es.near_cnt + (size_t)list * B, es.near_ids + (size_t)list * B * SKV_NEAR_MAX, es.near_pub + (size_t)list * B * SKV_NEAR_MAX,
                     es.early_of, es.staging, v_host, host_block_stride / 8, B * parts, n_chunks, E, parts, 64 * list,
                     es.near_cnt + (size_t)(1 - list) * B, es.near_ids + (size_t)(1 - list) * B * SKV_NEAR_MAX,

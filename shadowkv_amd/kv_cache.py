@@ -896,7 +896,7 @@ class ShadowKVCache_CPU:
         vhost = self.v_cache_cpu[layer_idx]
         args = (ptr(ea["states"][layer_idx]), ea["blocks"], self.num_key_value_groups, ea["n_lm"], ea["n_chunks"], ea["E"],
                 ptr(vhost), vhost.stride(1), self.near_pull_parts or max(1, min(4, 8 // ea["blocks"])))
-        return args if which == 0 else args + (which,)
+        return args + ((self.near_lists,) if which == 0 else (which,))      # (gate/up: how many lists are staged; down: which list)
 
     def near_published_ids(self, layer_idx):
         """int32 [blocks, 128]: the chunks staged AHEAD (near misses of an earlier step) in staging slots E .. E + 127
