@@ -270,6 +270,7 @@ class ShadowKVCache_CPU:
         # launch of every layer stages the chunks that fell just short of this step's selection (near_pull_args ->
         # tensor_op.norm_linear_decode(near_pull=)); the next step's fetch launch reads them from HBM.  Identical results.
         self.near_fetch = False
+        self._near_listed = -1           # layer whose selection of this step left its near-miss lists (near_pull_args)
         self.near_pull_parts = None      # pull workgroups per (batch, head): None = about 8 in all (1 for 8 KV heads, 2 for 4)
         self.near_lists = 1              # 1: only the gate/up launch stages (ranks S+1 .. S+64); 2: the down projection stages S+65 .. S+128
         #                                  too - measured 217.3 tokens/s against 230.8 with one list (226.8 with none): the 20 us down GEMV is
@@ -309,6 +310,7 @@ class ShadowKVCache_CPU:
             self._early = None
         self._pending_v = None
         self._early_pub = None
+        self._near_listed = -1
         self._pushed = None
         self._last_cos_sin = None
         self._staged_layer = -1
