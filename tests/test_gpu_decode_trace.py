@@ -75,7 +75,38 @@ def _fixture(case):
         return json.load(f)
 
 
+def _check_step_inplace(case, z, t, l, dev, mir):
+    """The reference-shaped methods on the IN-PLACE layout (kv_cache.inplace_methods): hits keep their slots, so the slot order
+    differs from the recording's - the chunk SET per head, the hit counts, the views' shapes and the bookkeeping must not; every
+    slot holds the V rows of the chunk it names (== the mirror's rows of that chunk, which are the recording's)."""
+    want = z["snapshots"][t][l]
+    S, C = dev.select_sets, dev.chunk_size
+    kv = dev.num_key_value_heads
+    ids = dev.position_ids[l][0].cpu()
+    want_ids = torch.tensor(want["position_ids"]).view(kv, S)
+    for h in range(kv):
+        assert sorted(ids[h].tolist()) == sorted(want_ids[h].tolist()), f"{case} step {t} layer {l} head {h}: chunk set"
+    assert dev.cnts.cpu().flatten().tolist() == want["cnts"], f"{case} step {t} layer {l}: cnts"
+    for key, val in (("k_view_shape", list(dev._last_k_view.shape)), ("v_view_shape", list(dev._last_v_view.shape)),
+                     ("kv_offset", int(dev.kv_offset)), ("gen_offset", int(dev.gen_offset)), ("kv_len", int(dev.get_kv_len()))):
+        assert val == want[key], f"{case} step {t} layer {l}: {key}"
+    assert digest(mir.v_cache_buffer[l]) == want["v_buffer"]
+    vdev, vmir = dev.v_cache_buffer[l][0].cpu(), mir.v_cache_buffer[l][0]
+    s0 = dev.sparse_start
+    mir_ids = mir.position_ids[l][0]
+    for h in range(kv):
+        slot_of = {int(c): j for j, c in enumerate(mir_ids[h].tolist())}
+        for j, c in enumerate(ids[h].tolist()):
+            a = vdev[h, s0 + j * C:s0 + (j + 1) * C]
+            b = vmir[h, s0 + slot_of[c] * C:s0 + (slot_of[c] + 1) * C]
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"{case} step {t} layer {l} head {h} slot {j}: V rows of chunk {c}"
+    assert_bits_equal(vmir[:, :s0], vdev[:, :s0], "local + outlier V rows")
+    assert_bits_equal(vmir[:, dev.sparse_end:], vdev[:, dev.sparse_end:], "generated V rows")
+
+
 def _check_step(case, z, t, l, dev, mir, k_diffs):
+    if dev.inplace_methods:
+        return _check_step_inplace(case, z, t, l, dev, mir)
     want = z["snapshots"][t][l]
     got = TD.snapshot(dev, l, dev.position_ids[l], dev._last_v_view, dev._last_k_view)
     for key in ("position_ids", "offsets", "cnts", "signals", "returned_ids", "v_buffer", "v_view", "k_view_shape",
@@ -183,4 +214,12 @@ def test_deferred_value_fetch_and_early_fetch_on_the_device(case, monkeypatch):
         dev.lazy_value_fetch = True
         if dev.early_fetch_supported():
             dev.enable_early_fetch()
+    _drive(case, monkeypatch, configure, streams=True)
+
+
+@pytest.mark.parametrize("case", list(G.TRACE_CASES))
+def test_reference_shaped_methods_on_the_in_place_layout(case, monkeypatch):
+    def configure(dev):
+        dev.lazy_value_fetch = True
+        dev.inplace_methods = True
     _drive(case, monkeypatch, configure, streams=True)
