@@ -31,6 +31,9 @@ TRACE_CASES = {
                               chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9202),
     "trace_glm_small": dict(layers=2, q_heads=32, kv_heads=4, head_dim=128, L=2048, budget=256,
                             chunk=8, rank=160, rope_theta=10000.0, glm=True, seed=9303),
+    # two sequences per cache: the batch dimension of every argument that crosses the native boundary (blocks = bs x kv heads)
+    "trace_llama_bs2": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=2048, budget=256, batch=2,
+                            chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9505),
 }
 TRACE_STEPS = 4
 
@@ -141,29 +144,33 @@ def rope_torch(case, x, cos_sin, position_ids):
 
 
 def trace_new_token(case, step, layer):
-    """The decoded token's K (as handed to update_kv_cache: post-RoPE, any bf16 values will do) and V, [1, kv, 1, D]."""
+    """The decoded token's K (as handed to update_kv_cache: post-RoPE, any bf16 values will do) and V, [bs, kv, 1, D]."""
     c = TRACE_CASES[case]
-    g = torch.Generator().manual_seed(c["seed"] * 31 + step * 17 + layer * 5 + 1)
-    k = torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16)
-    v = torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16)
-    return k, v
+    ks, vs = [], []
+    for b in range(c.get("batch", 1)):
+        g = torch.Generator().manual_seed(c["seed"] * 31 + step * 17 + layer * 5 + 1 + 7919 * b)
+        ks.append(torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16))
+        vs.append(torch.randn(1, c["kv_heads"], 1, c["head_dim"], generator=g).to(torch.bfloat16))
+    return torch.cat(ks), torch.cat(vs)
 
 
 def trace_query_draw(case, q_prev, step, layer, attempt):
-    """Random-walk query of (step, layer), draw number `attempt`: [1, q_heads, 1, D] bf16 from the previous accepted one."""
+    """Random-walk query of (step, layer), draw number `attempt`: [bs, q_heads, 1, D] bf16 from the previous accepted one."""
     c = TRACE_CASES[case]
     g = torch.Generator().manual_seed(((c["seed"] * 131 + step) * 31 + layer) * 4099 + attempt)
     return (q_prev.float() + 0.5 * torch.randn(q_prev.shape, generator=g)).to(torch.bfloat16)
 
 
 def trace_query(case, q_prev, step, layer, attempts):
-    """The query of (step, layer): the q heads of KV group h come from draw number attempts[h].  The fixture generator takes,
-    per KV head, the first draw whose top-k boundary is unique (any correct top-k then returns the same SET - the reference
-    leaves membership under ties undefined) and stores the numbers; the groups are independent."""
+    """The query of (step, layer): the q heads of KV group h of sequence b come from draw number attempts[b * kv + h].  The
+    fixture generator takes, per (sequence, KV head), the first draw whose top-k boundary is unique (any correct top-k then
+    returns the same SET - the reference leaves membership under ties undefined, SURVEY.md section 8a) and stores the numbers;
+    the groups are independent."""
     c = TRACE_CASES[case]
-    kv, groups = c["kv_heads"], c["q_heads"] // c["kv_heads"]
+    kv, groups, bs = c["kv_heads"], c["q_heads"] // c["kv_heads"], c.get("batch", 1)
     draws = {a: trace_query_draw(case, q_prev, step, layer, a) for a in set(attempts)}
-    return torch.cat([draws[attempts[h]][:, h * groups:(h + 1) * groups] for h in range(kv)], dim=1).contiguous()
+    return torch.cat([torch.cat([draws[attempts[b * kv + h]][b:b + 1, h * groups:(h + 1) * groups] for h in range(kv)], dim=1)
+                      for b in range(bs)], dim=0).contiguous()
 
 
 # ---- selection stage at the headline size (tests/golden/select_122k.npz) ------------------------------------

@@ -267,7 +267,7 @@ def run_trace(case):
     c = G.TRACE_CASES[case]
     trace = KernelTrace()
     ref = load_reference_offload(trace.module())
-    cache = ref.ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+    cache = ref.ShadowKVCache_CPU(G.config_of(case), batch_size=c.get("batch", 1), max_length=c["L"], device="cpu", dtype=torch.bfloat16,
                                   sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
     inputs = TD.layer_inputs(case)
     TD.prefill(cache, case, inputs)

@@ -14,8 +14,12 @@ def layer_inputs(case):
     c = G.TRACE_CASES[case]
     out = []
     for l in range(c["layers"]):
-        inp = G.make_inputs(case, layer=l)
-        inp["k_roped"] = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+        per = []
+        for b in range(c.get("batch", 1)):           # (sequence b of layer l: another draw; b = 0 is the single-sequence input)
+            inp = G.make_inputs(case, layer=l + 100 * b)
+            inp["k_roped"] = G.rope_torch(case, inp["k_pre"], inp["cos_sin"], torch.arange(c["L"]).unsqueeze(0))
+            per.append(inp)
+        inp = {k: (torch.cat([p[k] for p in per]) if k in ("k_pre", "v", "q_last", "k_roped") else per[0][k]) for k in per[0]}
         out.append(inp)
     return out
 
@@ -60,6 +64,7 @@ def decode(cache, case, inputs, trace=None, q_try=None, max_tries=4000, device="
     Returns (snapshots [step][layer], q_try [step][layer], q_digest [step][layer])."""
     c = G.TRACE_CASES[case]
     kv, groups, S = c["kv_heads"], c["q_heads"] // c["kv_heads"], c["budget"] // c["chunk"]
+    bs = c.get("batch", 1)
     cos_sin = inputs[0]["cos_sin"].to(device)
     q_prev = [inp["q_last"] for inp in inputs]
     snaps, tries, qd = [], [], []
@@ -70,11 +75,15 @@ def decode(cache, case, inputs, trace=None, q_try=None, max_tries=4000, device="
                 trace.mark([t, l])
             knew, vnew = G.trace_new_token(case, t, l)
             if q_try is None:
-                lm = cache.k_landmark[l][0].cpu()
-                a = [-1] * kv
+                lms = [cache.k_landmark[l][b].cpu() for b in range(bs)]
+                a = [-1] * (bs * kv)
                 for n in range(max_tries):
-                    ok = boundary_unique(lm, G.trace_query_draw(case, q_prev[l], t, l, n), kv, groups, S)
-                    a = [n if (a[h] < 0 and bool(ok[h])) else a[h] for h in range(kv)]
+                    draw = G.trace_query_draw(case, q_prev[l], t, l, n)
+                    for b in range(bs):
+                        ok = boundary_unique(lms[b], draw[b:b + 1], kv, groups, S)
+                        for h in range(kv):
+                            if a[b * kv + h] < 0 and bool(ok[h]):
+                                a[b * kv + h] = n
                     if min(a) >= 0:
                         break
                 else:
@@ -83,7 +92,7 @@ def decode(cache, case, inputs, trace=None, q_try=None, max_tries=4000, device="
                 a = list(q_try[t][l])
             q = G.trace_query(case, q_prev[l], t, l, a)
             if q_try is None:
-                assert bool(boundary_unique(lm, q, kv, groups, S).all())
+                assert all(bool(boundary_unique(lms[b], q[b:b + 1], kv, groups, S).all()) for b in range(bs))
             q_prev[l] = q
             tries[-1].append(a); qd[-1].append(digest(q))
             cache.update_kv_cache(knew.to(device), vnew.to(device), l)

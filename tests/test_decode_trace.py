@@ -43,7 +43,7 @@ def patched_kernels(monkeypatch, trace):
 def build_cpu_cache(case):
     from shadowkv_amd.kv_cache import ShadowKVCache_CPU
     c = G.TRACE_CASES[case]
-    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device="cpu", dtype=torch.bfloat16,
+    cache = ShadowKVCache_CPU(G.config_of(case), batch_size=c.get("batch", 1), max_length=c["L"], device="cpu", dtype=torch.bfloat16,
                               sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
     cache.reference_calls = True
     inputs = TD.layer_inputs(case)

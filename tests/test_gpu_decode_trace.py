@@ -37,7 +37,7 @@ STATE_SCALARS = ("prefill", "max_ctx_chunks_len", "chunks", "prefill_local", "sp
 def _new_cache(case, device):
     from shadowkv_amd.kv_cache import ShadowKVCache_CPU
     c = G.TRACE_CASES[case]
-    return ShadowKVCache_CPU(G.config_of(case), batch_size=1, max_length=c["L"], device=device, dtype=torch.bfloat16,
+    return ShadowKVCache_CPU(G.config_of(case), batch_size=c.get("batch", 1), max_length=c["L"], device=device, dtype=torch.bfloat16,
                              sparse_budget=c["budget"], chunk_size=c["chunk"], rank=c["rank"])
 
 
@@ -81,8 +81,8 @@ def _check_step_inplace(case, z, t, l, dev, mir):
     slot holds the V rows of the chunk it names (== the mirror's rows of that chunk, which are the recording's)."""
     want = z["snapshots"][t][l]
     S, C = dev.select_sets, dev.chunk_size
-    kv = dev.num_key_value_heads
-    ids = dev.position_ids[l][0].cpu()
+    kv = dev.block_num                                              # (batch x KV heads)
+    ids = dev.position_ids[l].flatten(0, 1).cpu()
     want_ids = torch.tensor(want["position_ids"]).view(kv, S)
     for h in range(kv):
         assert sorted(ids[h].tolist()) == sorted(want_ids[h].tolist()), f"{case} step {t} layer {l} head {h}: chunk set"
@@ -91,9 +91,9 @@ def _check_step_inplace(case, z, t, l, dev, mir):
                      ("kv_offset", int(dev.kv_offset)), ("gen_offset", int(dev.gen_offset)), ("kv_len", int(dev.get_kv_len()))):
         assert val == want[key], f"{case} step {t} layer {l}: {key}"
     assert digest(mir.v_cache_buffer[l]) == want["v_buffer"]
-    vdev, vmir = dev.v_cache_buffer[l][0].cpu(), mir.v_cache_buffer[l][0]
+    vdev, vmir = dev.v_cache_buffer[l].flatten(0, 1).cpu(), mir.v_cache_buffer[l].flatten(0, 1)
     s0 = dev.sparse_start
-    mir_ids = mir.position_ids[l][0]
+    mir_ids = mir.position_ids[l].flatten(0, 1)
     for h in range(kv):
         slot_of = {int(c): j for j, c in enumerate(mir_ids[h].tolist())}
         for j, c in enumerate(ids[h].tolist()):
@@ -114,10 +114,10 @@ def _check_step(case, z, t, l, dev, mir, k_diffs):
         assert got[key] == want[key], f"{case} step {t} layer {l}: {key}"
     # K: the mirror's buffer is the recording's (digest) when this box's LAPACK returns the recording's SVD factors (see
     # _drive); the device's differs from the mirror's by MFMA-order flips only
-    kcpu = mir.k_cache_buffer[l][0]
+    kcpu = mir.k_cache_buffer[l].flatten(0, 1)                     # [batch x KV heads, rows, D]
     if mir.factors_pinned:
         assert digest(mir.k_cache_buffer[l]) == want["k_buffer"]
-    kgpu = dev.k_cache_buffer[l][0].cpu()
+    kgpu = dev.k_cache_buffer[l].flatten(0, 1).cpu()
     s0, s1, C = dev.sparse_start, dev.sparse_end, dev.chunk_size
     assert_bits_equal(kcpu[:, :s0], kgpu[:, :s0], f"{case} step {t} layer {l}: local + outlier K rows")
     assert_bits_equal(kcpu[:, s1:], kgpu[:, s1:], f"{case} step {t} layer {l}: generated K rows")
