@@ -956,8 +956,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher (no GPU call has been made and none is made in this process)
+    if args.gpus > 1 and ("WORLD_SIZE" not in os.environ or "RANK" not in os.environ):
+        # plain `python bench.py --gpus N` (no launcher set RANK / WORLD_SIZE): become the launcher (no GPU call has been made and
+        # none is made in this process)
         rc = launch_replicas(args.gpus, sys.argv[1:] if argv is None else list(argv))
         if rc:
             sys.exit(rc)
