@@ -31,6 +31,10 @@ TRACE_CASES = {
                               chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9202),
     "trace_glm_small": dict(layers=2, q_heads=32, kv_heads=4, head_dim=128, L=2048, budget=256,
                             chunk=8, rank=160, rope_theta=10000.0, glm=True, seed=9303),
+    # BASELINE.json config 0 (the reference's own CPU-runnable case): 4K context (L > 4096: models/base.py:299 takes the prefill
+    # branch), budget 256 -> 504 chunks, no outlier chunk, S = 32, 416 buffer rows
+    "trace_llama_cfg0": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=4104, budget=256,
+                             chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9606),
     # two sequences per cache: the batch dimension of every argument that crosses the native boundary (blocks = bs x kv heads)
     "trace_llama_bs2": dict(layers=2, q_heads=32, kv_heads=8, head_dim=128, L=2048, budget=256, batch=2,
                             chunk=8, rank=160, rope_theta=500000.0, glm=False, seed=9505),
