@@ -3,9 +3,9 @@
 tests/golden/trace_*.json were recorded by tests/golden/make_golden.py from the reference's unmodified
 `ShadowKVCache_CPU` (/root/reference/models/kv_cache.py:983-1176, 1227-1271) and `models/tensor_op.py:171-238`, running
 offline with `kernels.shadowkv` = tests/golden/trace_standin.py (records every argument, carries the call out through
-oracle/): 2 layers x 4 decode steps in LLM.layer_compute's order, four cases (budget 1024; budget 2048 with the
-headline's row layout: 48 outlier chunks, sparse region [448, 2496); GLM-4 shapes with the width-64 cos/sin table; two
-sequences per cache).
+oracle/): 2 layers x 4 decode steps in LLM.layer_compute's order, five cases (budget 1024; budget 2048 with the
+headline's row layout: 48 outlier chunks, sparse region [448, 2496); BASELINE config 0: L = 4104, budget 256; GLM-4 shapes
+with the width-64 cos/sin table; two sequences per cache).
 
 CPU tests (this file, no GPU): shadowkv_amd.kv_cache.ShadowKVCache_CPU with reference_calls=True, the same stand-in patched
 over shadowkv_amd.kernels.shadowkv, on the same seeded inputs ->
