@@ -434,7 +434,7 @@ def test_overlapped_attention_at_headline_shape_against_f32_oracle(kv_heads, glm
         cache.select_fetch_attend_inplace(0, q, cs, kv_len=cache.k_cache_buffer.shape[-2] + 1)
 
 
-@pytest.mark.parametrize("kv_heads,glm,overlap", [(8, False, True), (8, False, False), (4, True, True)])
+@pytest.mark.parametrize("kv_heads,glm,overlap", [(8, False, True), (8, False, False), (4, True, True), (8, False, "near")])
 def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm, overlap):
     """resident_sets = 512 > select_sets = 256 (in-place layout): over a walk of queries, step by step against a cache
     with the reference's resident set (256) fed the same queries - the selected sets are identical, the hit counts are
@@ -446,6 +446,12 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
     R = 512
     big, cs, g = _headline_cache(kv_heads, glm, resident_sets=R)
     ref, _, _ = _headline_cache(kv_heads, glm)
+    near = overlap == "near"     # (round 5: + the early fetch and the near-miss staging on the 512-slot cache - a chunk staged ahead
+    #                              may be resident but not selected there; what is attended and every slot's bytes must not change)
+    if near:
+        big.near_lists = 2
+        big.enable_early_fetch(near=True)
+        gw = torch.Generator(device=DEV).manual_seed(9)
     Hq, D, C, S = 32, 128, 8, big.select_sets
     assert big.sparse_end == 448 + R * C and big.k_cache_buffer.shape[-2] == 448 + R * C + 96 and ref.sparse_end == 2496
     gen = 2
@@ -470,6 +476,10 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
                 outs.append(tensor_op.sparse_attention_decode(q, c.k_cache_buffer[0], c.v_cache_buffer[0], kv_len=kv_len,
                                                               **c.attend_slot_args()))
         torch.cuda.synchronize()
+        if near:
+            _check_staging_invariant(big, 0)
+            _gate_up_with_near_pull(big, 0, gw)
+            _check_staging_invariant(big, 0)
         slots = big._dst_slots.view(kv_heads, S).cpu().long()                # the S attended slots per head
         ids_big = big.position_ids[0][0].cpu()
         sel_big = torch.gather(ids_big, 1, slots).sort(dim=-1).values
