@@ -519,7 +519,7 @@ def test_resident_set_of_512_chunks_attends_exactly_the_selection(kv_heads, glm,
                 kview, vview = kb[:, :, :c.sparse_end + gen].contiguous(), vb[:, :, :c.sparse_end + gen].contiguous()
                 n_att = kview.shape[2]
                 labels = standalone_pass_labels(1, Hq, kv_heads, n_att, tensor_op.default_attention_splits(1, kv_heads, kb.shape[2]))
-            check_attention(f"test_resident_set_of_512_chunks[kv{kv_heads}-glm{int(glm)}-overlap{int(overlap)}] step {step} {name}",
+            check_attention(f"test_resident_set_of_512_chunks[kv{kv_heads}-glm{int(glm)}-overlap{overlap if near else int(overlap)}] step {step} {name}",
                             o.view(1, Hq, D).cpu().float(), q.cpu().view(1, Hq, D).contiguous(), kview, vview, n_att, 1 / math.sqrt(D), labels)
     assert more_hits > 0, "the larger resident set never produced an extra hit"
     with pytest.raises(RuntimeError):
